@@ -1,0 +1,92 @@
+"""CPU restatement of the query processor's execution path (TEST INFRASTRUCTURE ONLY).
+
+The reference hands the translated SQL text to Spark SQL
+(QueryProcessor.executeFinalQuery, QueryProcessor.scala:184-195) over temp views
+named after the vertical-partition tables (preloadTables :210-236, loadDataset
+:308-339) and reports `result.count` (:173-176). Spark SQL itself
+(org.apache.spark:spark-sql_2.12:3.0.1, pom.xml:80-85) is a third-party
+dependency that is not in the reference tree and cannot run offline, so this
+checker executes the same SQL text, verbatim, with SQLite over the same tables:
+inner joins, equality on strings, bag semantics, UNION as set union -- the part
+of SQL both engines agree on.
+
+PARITY UNPINNED: the reference holds no expected counts or bindings for any
+query (SURVEY of its tests: one `assertTrue(true)`); results are checked against
+this restatement only.
+"""
+from __future__ import annotations
+
+import re
+import sqlite3
+
+
+def parse_translated_file(text: str):
+    """QueryProcessor.main, :68-88. Returns (query_map, partitions, tp_num)."""
+    partitions, tp_num, query_map = [], -1, {}
+    for line in re.split("\r\n|\n|\r", text):
+        if line.startswith("TP"):
+            tp_num = int(line.split(" ")[1])
+        elif line.startswith("partitions"):
+            partitions = line.split(" ")[1].split(",")
+        elif not line.startswith(">>>>>"):
+            tokens = line.split(" ")
+            query_map[tokens[0]] = " ".join(tokens[1:])
+    return query_map, partitions, tp_num
+
+
+def clean_table_name(partition: str) -> str:
+    """QueryProcessor.scala:216."""
+    return "table" + partition.replace("-", "_").replace("=", "_E_").strip()
+
+
+def _strip_union_parens(sql: str) -> str:
+    """Spark accepts `( (SELECT ..) UNION (SELECT ..) ) AS t`; SQLite wants the
+    arms of a compound select unparenthesised."""
+    return re.sub(r"\(\s*(\(SELECT.*?\)(?:\s*UNION\s*\(SELECT.*?\))+)\s*\)",
+                  lambda m: "(" + re.sub(r"\)\s*UNION\s*\(", " UNION ", m.group(1).strip()[1:-1]) + ")", sql)
+
+
+class SqliteProcessor:
+    """preloadTables + executeFinalQuery over in-memory (s, o) string tables."""
+
+    def __init__(self, vp: dict):
+        # vp: {(partition_name, '_3=<pred>'): [(s, o), ...]}
+        self.vp = vp
+        self.db = sqlite3.connect(":memory:")
+        self.loaded = set()
+
+    def preload(self, partitions):
+        rows_total = 0
+        for part in partitions:
+            name = clean_table_name(part)
+            pname, sub = part.split("-", 1)
+            rows = self.vp.get((pname, sub))
+            if rows is None:
+                raise FileNotFoundError(part)  # spark.read.load on a missing path throws
+            if name not in self.loaded:
+                self.db.execute('CREATE TABLE "%s" (s TEXT, o TEXT)' % name)
+                self.db.executemany('INSERT INTO "%s" VALUES (?, ?)' % name, rows)
+                self.loaded.add(name)
+            rows_total += len(rows)
+        return rows_total
+
+    def execute(self, query_map: dict):
+        """Returns (columns, rows) -- rows as a list of tuples of raw terms."""
+        if len(query_map) != 1:
+            raise NotImplementedError("multi-statement files are never produced by the translator")
+        sql = _strip_union_parens(next(iter(query_map.values())))
+        cur = self.db.execute(sql)
+        cols = [d[0] for d in cur.description]
+        return cols, cur.fetchall()
+
+
+def run_query(vp: dict, translated_text: str):
+    """Returns {'count', 'columns', 'rows' (sorted by the column names' order)}."""
+    qm, partitions, tp = parse_translated_file(translated_text)
+    proc = SqliteProcessor(vp)
+    loaded = proc.preload(partitions)
+    cols, rows = proc.execute(qm)
+    order = sorted(range(len(cols)), key=lambda i: cols[i])
+    cols_sorted = [cols[i] for i in order]
+    rows_sorted = sorted(tuple(r[i] for i in order) for r in rows)
+    return {"count": len(rows), "columns": cols_sorted, "rows": rows_sorted, "load_data": loaded, "tp": tp}
