@@ -1,0 +1,155 @@
+/* libdiaeresis_hip.so -- C ABI of the MI355X-native engine behind DIAERESIS' two hot paths.
+ *
+ * The reference (Scala on Spark) has no plugin or FFI seam: its partitioner and query processor
+ * call Spark directly. Each entry point below replaces a group of those call sites; the comment
+ * above it names them (paths relative to src/main/scala/org/ics/isl/ of the reference). A JVM host
+ * binds these with JNI or Panama; the repository's own CLIs and Python wrapper use them as they are.
+ *
+ * Conventions: one dx_ctx per GPU and per host thread (the reference's driver is single-threaded);
+ * calls block until the GPU work is done; 0 = success, negative = error (errno-style, below) with a
+ * message in dx_last_error(); plain pointers and sizes only; the library owns every device buffer
+ * except the ones explicitly passed in.
+ */
+#ifndef DIAERESIS_HIP_H
+#define DIAERESIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DX_OK 0
+#define DX_E_NOENT (-2)         /* table / file / term not found */
+#define DX_E_IO (-5)            /* read or write failed */
+#define DX_E_NOMEM (-12)        /* device or host allocation failed */
+#define DX_E_INVAL (-22)        /* bad argument */
+#define DX_E_RANGE (-34)        /* input exceeds a documented limit */
+#define DX_E_MALFORMED (-74)    /* input line or SQL text the reference would throw on */
+#define DX_E_UNSUPPORTED (-95)  /* valid for the reference but outside this engine's subset */
+#define DX_E_HIP (-1000)        /* HIP runtime error; text in dx_last_error */
+
+#define DX_MAX_PARTITIONS 64
+
+typedef struct dx_ctx dx_ctx;
+typedef struct dx_result dx_result;
+
+/* ---- context -------------------------------------------------------------------------------
+ * Replaces SparkSession.builder...getOrCreate() (partitioner/DAP.scala:41-48,
+ * query_processor/QueryProcessor.scala:116-154) and spark.stop() (DAP.scala:98, QueryProcessor.scala:109). */
+dx_ctx* dx_init(int device);
+void dx_free(dx_ctx* ctx);
+const char* dx_last_error(dx_ctx* ctx);
+
+/* ---- partitioner: the post-DAP stage ----------------------------------------------------------- */
+typedef struct dx_part_stats {
+  uint64_t n_bytes;         /* input text bytes */
+  uint64_t n_triples;       /* input records = lines not starting with '#' (DAP.scala:83 counts all lines) */
+  uint64_t n_unique;        /* distinct (s, p, o) */
+  uint64_t n_terms;         /* dictionary size */
+  uint64_t n_vertices;      /* Preprocessor.scala:131-143 */
+  uint64_t n_edges;         /* Preprocessor.scala:153-167 */
+  uint64_t n_rows;          /* rows over all first-level partitions (replicas counted) */
+  uint64_t n_node_index;    /* rows of node_index_N */
+  uint64_t n_vp_index;      /* (uri, role, predicate) entries over all partitions */
+  uint32_t n_predicates;
+  uint32_t n_tables;        /* non-empty (partition, predicate) vertical-partition tables */
+  uint32_t hash_retries;    /* dictionary rebuilds caused by a true 64-bit hash collision */
+  uint32_t reserved;
+  double ms_total;          /* device time of the whole call, inputs already in HBM */
+  double ms_stage[12];      /* see dx_part_stage_name() */
+} dx_part_stats;
+
+/* Replaces, in one call, Preprocessor.createInstanceGraph (Preprocessor.scala:116-192, minus the
+ * parquet writes), Loader.loadInstanceGraph (Loader.scala:19-38), Loader.loadClassIndexBal
+ * (Loader.scala:114-123), DAP.partitionInstances (partitioner/DAP.scala:567-629),
+ * DAP.partitionClusters (:360-382), DAP.subPartitionClusters (:385-509) and
+ * DAP.computePartitionStatistics (:101-114), for N-Triples text that is already resident in HBM.
+ * d_text: device pointer to n_bytes of UTF-8 text. class_index_text: contents of
+ * <dataset>_local/class_index.txt_<N>_bal (host string, NUL-terminated). Results stay in HBM inside
+ * ctx (replacing any earlier run) until dx_free; read them with the dx_part_* accessors, register
+ * them for queries with dx_load_table, or persist them with dx_part_write_layout. */
+int dx_partition_device(dx_ctx* ctx, const void* d_text, uint64_t n_bytes, const char* class_index_text,
+                        int n_partitions, dx_part_stats* stats);
+/* Same, reading the instances file and the class index file from the local file system. */
+int dx_partition_file(dx_ctx* ctx, const char* instances_path, const char* class_index_path, int n_partitions,
+                      dx_part_stats* stats);
+const char* dx_part_stage_name(int i);
+
+/* Dictionary (replaces the strings Spark carries through every stage; ids are int64, dense, assigned
+ * in order of first occurrence in the input). */
+int64_t dx_term_count(dx_ctx* ctx);
+/* Sum of the byte lengths of the given terms (to size the buffer of dx_terms_decode). id < 0 or >= count -> DX_E_RANGE. */
+int dx_terms_bytes(dx_ctx* ctx, const int64_t* ids, uint64_t n, uint64_t* total_bytes);
+/* Concatenated UTF-8 bytes of the terms; offsets[n+1] delimit them. */
+int dx_terms_decode(dx_ctx* ctx, const int64_t* ids, uint64_t n, char* bytes, uint64_t cap, uint64_t* offsets);
+/* ids[i] = id of the i-th string, or -1 when it is not in the dictionary. */
+int dx_terms_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids);
+
+/* First-level partitions (DAP.scala:364-367: one part file per partition, columns _1=s,_2=o,_3=p). */
+int dx_part_count(dx_ctx* ctx);
+int64_t dx_part_rows(dx_ctx* ctx, int partition);
+/* Copies the partition's rows to host arrays (each of dx_part_rows entries); p holds predicate term ids. */
+int dx_part_fetch(dx_ctx* ctx, int partition, int64_t* s, int64_t* o, int64_t* p);
+
+/* Vertical-partition tables (DAP.scala:419-437). Table i is (partition, predicate term). */
+typedef struct dx_table_info {
+  int32_t partition;
+  int32_t in_layout;        /* 0 when the predicate has >= 150 UTF-16 units and is left out of the VP dirs (DAP.scala:434) */
+  int64_t predicate;        /* term id */
+  int64_t rows;
+} dx_table_info;
+int dx_table_count(dx_ctx* ctx);
+int dx_table_info_at(dx_ctx* ctx, int i, dx_table_info* out);
+int dx_table_fetch(dx_ctx* ctx, int i, int64_t* s, int64_t* o);
+
+/* node_index_N (DAP.scala:402-412): distinct (uri, type) pairs. */
+int64_t dx_node_index_rows(dx_ctx* ctx);
+int dx_node_index_fetch(dx_ctx* ctx, int64_t* uri, int64_t* type);
+
+/* classSubPart_index_N__0000i (DAP.scala:450-501), as (uri, role, predicate) with role 0 = 's', 1 = 'o'. */
+int64_t dx_vp_index_rows(dx_ctx* ctx, int partition);
+int dx_vp_index_fetch(dx_ctx* ctx, int partition, int64_t* uri, int32_t* role, int64_t* predicate);
+
+/* Instance graph of Preprocessor.scala:142-167: vertex term ids in String.compareTo order (position =
+ * the reference's vertex id) and the distinct edges as (src position, dst position, predicate term id). */
+int dx_instance_graph_sizes(dx_ctx* ctx, int64_t* n_vertices, int64_t* n_edges);
+int dx_instance_graph_fetch(dx_ctx* ctx, int64_t* vertex_terms, int64_t* edge_src, int64_t* edge_dst, int64_t* edge_pred);
+
+/* Writes <base><dataset>_data/... and <dataset>_local/... as the reference lays them out
+ * (Constatnts.scala:9-40), with int64 column files beside the directory names the Scala tools expect. */
+int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
+
+/* ---- query processor ------------------------------------------------------------------------------ */
+/* Points the context at a layout written by dx_part_write_layout (replaces the path arithmetic of
+ * QueryProcessor.loadDataset, QueryProcessor.scala:308-325) and loads its dictionary. */
+int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions);
+/* Replaces QueryProcessor.loadDataset + preloadTables (QueryProcessor.scala:210-236, 308-339) for one
+ * entry of the `partitions` line ("00001-_3=<sanitised predicate>"): makes the table resident in HBM and
+ * visible to SQL under "table" + key with '-' -> '_' and '=' -> '_E_' (:216). Memoised like dataMap (:327-337). */
+int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows);
+/* Replaces unloadTables (QueryProcessor.scala:239-251). */
+int dx_unload_all(dx_ctx* ctx);
+
+#define DX_QUERY_COUNT 0        /* what the warm path times: result.count (QueryProcessor.scala:173-176) */
+#define DX_QUERY_BINDINGS 1     /* materialise bindings (QueryProcessorCold.scala:119-127) */
+/* Replaces executeFinalQuery -> spark.sqlContext.sql(query) (QueryProcessor.scala:184-195) followed by
+ * result.count. sql is one statement of the translated-query grammar (QueryTranslator.scala:363-392, 417-543). */
+int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out);
+uint64_t dx_result_count(dx_result* r);
+int dx_result_columns(dx_result* r);
+const char* dx_result_column_name(dx_result* r, int i);
+/* Rows as term ids, column-major (column i at ids + i * count), sorted by the decoded strings of the
+ * columns in name order when sorted != 0. Needs DX_QUERY_BINDINGS. */
+int dx_result_fetch_ids(dx_result* r, int64_t* ids, int sorted);
+/* Ids <= -2 in a result are constants projected by the statement itself (`'<...>' AS P`,
+ * QueryTranslator.scala:485-526), which are not dictionary terms; this returns their text, or NULL. */
+const char* dx_result_virtual_term(dx_result* r, int64_t id);
+/* Device time of the statement in milliseconds (hipEvents around the launches). */
+double dx_result_device_ms(dx_result* r);
+void dx_result_free(dx_result* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,716 @@
+// C ABI of libdiaeresis_hip.so: context, accessors, on-disk layout, query entry points.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <fstream>
+#include <sstream>
+
+#include "dx_device.h"
+#include "dx_state.h"
+
+namespace dx {
+uint64_t hash_bytes_host(const uint8_t* p, size_t n, uint64_t seed) {
+  TermHash h(seed);
+  for (size_t i = 0; i < n; ++i) h.add(p[i]);
+  return h.finish((uint32_t)n);
+}
+
+namespace {
+
+template <typename F>
+int guard(dx_ctx* ctx, F&& f) {
+  if (!ctx) return DX_E_INVAL;
+  try {
+    DX_HIP(hipSetDevice(ctx->device));
+    f();
+    return DX_OK;
+  } catch (const DxError& e) {
+    ctx->err = e.what();
+    return e.code;
+  } catch (const HipError& e) {
+    ctx->err = e.what();
+    return DX_E_HIP;
+  } catch (const std::bad_alloc&) {
+    ctx->err = "host allocation failed";
+    return DX_E_NOMEM;
+  } catch (const std::exception& e) {
+    ctx->err = e.what();
+    return DX_E_INVAL;
+  }
+}
+
+std::vector<ClassIndexEntry> parse_class_index(const std::string& text, int nparts) {
+  // Loader.loadClassIndexBal (Loader.scala:114-123): `class \t p1,p2,...`; a later line replaces an earlier one
+  std::map<std::string, uint64_t> m;
+  std::istringstream in(text);
+  std::string line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    const size_t tab = line.find('\t');
+    const std::string cls = line.substr(0, tab);
+    std::string rest;
+    if (tab != std::string::npos)
+      for (char c : line.substr(tab + 1))
+        if (c != '\t') rest += c;  // tokens.drop(1).mkString
+    uint64_t mask = 0;
+    std::istringstream ps(rest);
+    std::string tok;
+    while (std::getline(ps, tok, ',')) {
+      char* end = nullptr;
+      errno = 0;
+      const long v = strtol(tok.c_str(), &end, 10);
+      if (tok.empty() || *end || errno) throw DxError(DX_E_MALFORMED, "class index: bad partition id '" + tok + "' for " + cls);
+      if (v < 0 || v >= nparts)
+        throw DxError(DX_E_RANGE, "class index: partition " + tok + " outside [0, " + std::to_string(nparts) + ") for " + cls);
+      mask |= 1ull << v;
+    }
+    m[cls] = mask;
+  }
+  std::vector<ClassIndexEntry> out;
+  for (auto& kv : m) out.push_back({kv.first, kv.second});
+  return out;
+}
+
+std::string read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw DxError(DX_E_NOENT, "cannot open " + path);
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+void mkdirs(const std::string& path) {
+  std::string cur;
+  for (size_t i = 0; i < path.size(); ++i) {
+    cur += path[i];
+    if (path[i] == '/' || i + 1 == path.size()) {
+      if (cur == "/" || cur.empty()) continue;
+      if (mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) throw DxError(DX_E_IO, "mkdir " + cur + ": " + strerror(errno));
+    }
+  }
+}
+
+struct ColHeader {
+  char magic[8];
+  uint64_t rows;
+  uint64_t ncols;
+};
+const char kMagic[8] = {'D', 'X', 'C', 'O', 'L', '1', 0, 0};
+
+void write_cols(const std::string& path, uint64_t rows, const std::vector<const int64_t*>& host_cols) {
+  std::ofstream f(path, std::ios::binary | std::ios::trunc);
+  if (!f) throw DxError(DX_E_IO, "cannot create " + path);
+  ColHeader h;
+  memcpy(h.magic, kMagic, 8);
+  h.rows = rows;
+  h.ncols = host_cols.size();
+  f.write((const char*)&h, sizeof h);
+  for (auto* c : host_cols) f.write((const char*)c, (std::streamsize)(rows * 8));
+  if (!f) throw DxError(DX_E_IO, "write failed: " + path);
+}
+void touch(const std::string& path) { std::ofstream f(path, std::ios::trunc); }
+
+std::string part_name(int i) {
+  char b[16];
+  snprintf(b, sizeof b, "%05d", i);
+  return b;
+}
+std::string norm_base(const char* base) {
+  std::string b = base ? base : "";
+  if (!b.empty() && b.back() != '/') b += '/';  // DAP.scala:67-68
+  return b;
+}
+std::string view_name(const std::string& key) {  // QueryProcessor.scala:216
+  std::string v = "table";
+  for (char c : key) {
+    if (c == '-') v += '_';
+    else if (c == '=') v += "_E_";
+    else v += c;
+  }
+  size_t b = 5, e = v.size();
+  while (e > b && (unsigned char)v[e - 1] <= ' ') --e;
+  return v.substr(0, e);
+}
+
+void fetch(void* dst, const void* src, size_t bytes) {
+  if (bytes) DX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+}
+
+// java.lang.String.compareTo on UTF-8 bytes: code-unit order differs from byte order only between
+// supplementary characters (lead byte 0xF0-0xF4, surrogates 0xD800-0xDFFF in UTF-16) and U+E000-U+FFFF
+// (lead byte 0xEE/0xEF).
+inline int utf16_rank(unsigned char c) { return (c == 0xEE || c == 0xEF) ? c + 0x10 : c; }
+bool utf16_less(const uint8_t* a, size_t la, const uint8_t* b, size_t lb) {
+  const size_t n = std::min(la, lb);
+  for (size_t i = 0; i < n; ++i)
+    if (a[i] != b[i]) return utf16_rank(a[i]) < utf16_rank(b[i]);
+  if (la == lb) return false;
+  // a proper prefix is smaller -- but a supplementary character counts two units, which never changes
+  // which string is the prefix
+  return la < lb;
+}
+
+}  // namespace
+}  // namespace dx
+
+using namespace dx;
+
+extern "C" {
+
+dx_ctx* dx_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  auto* ctx = new dx_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return nullptr;
+  }
+  return ctx;
+}
+
+void dx_free(dx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->catalog.clear();
+  ctx->part = PartitionState();
+  ctx->dict = Dictionary();
+  ctx->qws.reset();
+  ctx->pool.trim();
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* dx_last_error(dx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char* dx_part_stage_name(int i) { return (i >= 0 && i < 12) ? kStageNames[i] : ""; }
+
+int dx_partition_device(dx_ctx* ctx, const void* d_text, uint64_t n_bytes, const char* class_index_text, int n_partitions,
+                        dx_part_stats* stats) {
+  return guard(ctx, [&] {
+    if (!class_index_text || (!d_text && n_bytes)) throw DxError(DX_E_INVAL, "null argument");
+    if (n_partitions < 1 || n_partitions > DX_MAX_PARTITIONS) throw DxError(DX_E_INVAL, "n_partitions must be in [1, 64]");
+    const auto classes = parse_class_index(class_index_text, n_partitions);
+    run_partition(ctx, (const uint8_t*)d_text, n_bytes, classes, n_partitions);
+    if (stats) *stats = ctx->part.stats;
+  });
+}
+
+int dx_partition_file(dx_ctx* ctx, const char* instances_path, const char* class_index_path, int n_partitions,
+                      dx_part_stats* stats) {
+  return guard(ctx, [&] {
+    if (!instances_path || !class_index_path) throw DxError(DX_E_INVAL, "null path");
+    const std::string ci = read_file(class_index_path);
+    std::ifstream f(instances_path, std::ios::binary | std::ios::ate);
+    if (!f) throw DxError(DX_E_NOENT, std::string("cannot open ") + instances_path);
+    const uint64_t n = (uint64_t)f.tellg();
+    f.seekg(0);
+    DevBuf<uint8_t> text(ctx->pool, n + 16);
+    // stream through a pinned staging buffer: the file never has to fit in host memory
+    const size_t chunk = 64u << 20;
+    void* stage = nullptr;
+    DX_HIP(hipHostMalloc(&stage, chunk, hipHostMallocDefault));
+    try {
+      for (uint64_t done = 0; done < n;) {
+        const size_t want = (size_t)std::min<uint64_t>(chunk, n - done);
+        f.read((char*)stage, (std::streamsize)want);
+        if ((size_t)f.gcount() != want) throw DxError(DX_E_IO, std::string("short read on ") + instances_path);
+        DX_HIP(hipMemcpy(text.p + done, stage, want, hipMemcpyHostToDevice));
+        done += want;
+      }
+    } catch (...) {
+      (void)hipHostFree(stage);
+      throw;
+    }
+    (void)hipHostFree(stage);
+    const auto classes = parse_class_index(ci, n_partitions);
+    run_partition(ctx, text.p, n, classes, n_partitions);
+    if (stats) *stats = ctx->part.stats;
+  });
+}
+
+// ---- dictionary -----------------------------------------------------------------------------------
+int64_t dx_term_count(dx_ctx* ctx) { return ctx && ctx->dict.valid() ? (int64_t)ctx->dict.n_terms : -1; }
+
+static void term_offsets(dx_ctx* ctx, const int64_t* ids, uint64_t n, std::vector<uint64_t>& begin, std::vector<uint64_t>& len) {
+  const Dictionary& d = ctx->dict;
+  if (!d.valid()) throw DxError(DX_E_INVAL, "no dictionary");
+  std::vector<uint64_t> off(d.n_terms + 1);
+  fetch(off.data(), d.pool_off.p, (d.n_terms + 1) * 8);
+  begin.resize(n);
+  len.resize(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (ids[i] < 0 || (uint64_t)ids[i] >= d.n_terms) throw DxError(DX_E_RANGE, "term id out of range: " + std::to_string(ids[i]));
+    begin[i] = off[ids[i]];
+    len[i] = off[ids[i] + 1] - off[ids[i]];
+  }
+}
+
+int dx_terms_bytes(dx_ctx* ctx, const int64_t* ids, uint64_t n, uint64_t* total_bytes) {
+  return guard(ctx, [&] {
+    std::vector<uint64_t> b, l;
+    term_offsets(ctx, ids, n, b, l);
+    uint64_t t = 0;
+    for (auto x : l) t += x;
+    *total_bytes = t;
+  });
+}
+
+int dx_terms_decode(dx_ctx* ctx, const int64_t* ids, uint64_t n, char* bytes, uint64_t cap, uint64_t* offsets) {
+  return guard(ctx, [&] {
+    std::vector<uint64_t> b, l;
+    term_offsets(ctx, ids, n, b, l);
+    const Dictionary& d = ctx->dict;
+    std::vector<uint8_t> pool(d.pool_off.n ? 0 : 0);
+    uint64_t pool_bytes = 0;
+    fetch(&pool_bytes, d.pool_off.p + d.n_terms, 8);
+    uint64_t total = 0;
+    for (auto x : l) total += x;
+    if (total > cap) throw DxError(DX_E_RANGE, "decode buffer too small");
+    // bulk requests copy the pool once; small ones copy term by term
+    if (n > 4096) {
+      pool.resize(pool_bytes);
+      fetch(pool.data(), d.pool.p, pool_bytes);
+    }
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      offsets[i] = w;
+      if (n > 4096) memcpy(bytes + w, pool.data() + b[i], l[i]);
+      else fetch(bytes + w, d.pool.p + b[i], l[i]);
+      w += l[i];
+    }
+    offsets[n] = w;
+  });
+}
+
+int dx_terms_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids) {
+  return guard(ctx, [&] { dict_lookup(ctx, bytes, offsets, n, ids); });
+}
+
+// ---- partitions, tables, indexes -------------------------------------------------------------------
+int dx_part_count(dx_ctx* ctx) { return ctx && ctx->part.valid ? ctx->part.n_partitions : -1; }
+
+int64_t dx_part_rows(dx_ctx* ctx, int q) {
+  if (!ctx || !ctx->part.valid || q < 0 || q >= ctx->part.n_partitions) return -1;
+  return (int64_t)(ctx->part.part_base[q + 1] - ctx->part.part_base[q]);
+}
+
+int dx_part_fetch(dx_ctx* ctx, int q, int64_t* s, int64_t* o, int64_t* p) {
+  return guard(ctx, [&] {
+    const PartitionState& ps = ctx->part;
+    if (!ps.valid || q < 0 || q >= ps.n_partitions) throw DxError(DX_E_INVAL, "no such partition");
+    const uint64_t b = ps.part_base[q], n = ps.part_base[q + 1] - b;
+    fetch(s, ps.row_s.p + b, n * 8);
+    fetch(o, ps.row_o.p + b, n * 8);
+    std::vector<uint32_t> pi(n);
+    fetch(pi.data(), ps.row_p.p + b, n * 4);
+    for (uint64_t i = 0; i < n; ++i) p[i] = ps.pred_terms[pi[i]];
+  });
+}
+
+int dx_table_count(dx_ctx* ctx) { return ctx && ctx->part.valid ? (int)ctx->part.tables.size() : -1; }
+
+int dx_table_info_at(dx_ctx* ctx, int i, dx_table_info* out) {
+  return guard(ctx, [&] {
+    const PartitionState& ps = ctx->part;
+    if (!ps.valid || i < 0 || i >= (int)ps.tables.size() || !out) throw DxError(DX_E_INVAL, "no such table");
+    const VpTable& t = ps.tables[i];
+    out->partition = t.partition;
+    out->in_layout = t.in_layout ? 1 : 0;
+    out->predicate = t.pred_term;
+    out->rows = (int64_t)t.rows;
+  });
+}
+
+int dx_table_fetch(dx_ctx* ctx, int i, int64_t* s, int64_t* o) {
+  return guard(ctx, [&] {
+    const PartitionState& ps = ctx->part;
+    if (!ps.valid || i < 0 || i >= (int)ps.tables.size()) throw DxError(DX_E_INVAL, "no such table");
+    const VpTable& t = ps.tables[i];
+    fetch(s, ps.row_s.p + t.begin, t.rows * 8);
+    fetch(o, ps.row_o.p + t.begin, t.rows * 8);
+  });
+}
+
+int64_t dx_node_index_rows(dx_ctx* ctx) { return ctx && ctx->part.valid ? (int64_t)ctx->part.n_node : -1; }
+
+int dx_node_index_fetch(dx_ctx* ctx, int64_t* uri, int64_t* type) {
+  return guard(ctx, [&] {
+    const PartitionState& ps = ctx->part;
+    if (!ps.valid) throw DxError(DX_E_INVAL, "no partition run");
+    fetch(uri, ps.node_s.p, ps.n_node * 8);
+    fetch(type, ps.node_o.p, ps.n_node * 8);
+  });
+}
+
+int64_t dx_vp_index_rows(dx_ctx* ctx, int q) {
+  if (!ctx || !ctx->part.valid || q < 0 || q >= ctx->part.n_partitions) return -1;
+  return (int64_t)(ctx->part.vpi_base[q + 1] - ctx->part.vpi_base[q]);
+}
+
+int dx_vp_index_fetch(dx_ctx* ctx, int q, int64_t* uri, int32_t* role, int64_t* predicate) {
+  return guard(ctx, [&] {
+    const PartitionState& ps = ctx->part;
+    if (!ps.valid || q < 0 || q >= ps.n_partitions) throw DxError(DX_E_INVAL, "no such partition");
+    const uint64_t b = ps.vpi_base[q], n = ps.vpi_base[q + 1] - b;
+    std::vector<uint64_t> k(n);
+    fetch(k.data(), ps.vpi.p + b, n * 8);
+    const uint64_t pm = (1ull << ps.vpi_bits_pred) - 1, tm = (1ull << ps.vpi_bits_term) - 1;
+    for (uint64_t i = 0; i < n; ++i) {
+      predicate[i] = ps.pred_terms[k[i] & pm];
+      role[i] = (int32_t)((k[i] >> ps.vpi_bits_pred) & 1);
+      uri[i] = (int64_t)((k[i] >> (ps.vpi_bits_pred + 1)) & tm);
+    }
+  });
+}
+
+// ---- instance graph (export path; not on the timed path) -----------------------------------------------
+static void instance_graph(dx_ctx* ctx, std::vector<int64_t>& vterms, std::vector<int64_t>* es, std::vector<int64_t>* ed,
+                           std::vector<int64_t>* ep) {
+  const PartitionState& ps = ctx->part;
+  const Dictionary& d = ctx->dict;
+  if (!ps.valid) throw DxError(DX_E_INVAL, "no partition run");
+  std::vector<uint8_t> flags(d.n_terms);
+  fetch(flags.data(), ps.term_flags.p, d.n_terms);
+  std::vector<uint64_t> off(d.n_terms + 1);
+  fetch(off.data(), d.pool_off.p, (d.n_terms + 1) * 8);
+  std::vector<uint8_t> pool(off[d.n_terms]);
+  fetch(pool.data(), d.pool.p, pool.size());
+  vterms.clear();
+  for (uint64_t t = 0; t < d.n_terms; ++t)
+    if (flags[t] & 2) vterms.push_back((int64_t)t);
+  // sortByKey().zipWithIndex (Preprocessor.scala:142-143): rank in String.compareTo order
+  std::sort(vterms.begin(), vterms.end(), [&](int64_t a, int64_t b) {
+    return utf16_less(pool.data() + off[a], off[a + 1] - off[a], pool.data() + off[b], off[b + 1] - off[b]);
+  });
+  if (!es) return;
+  std::vector<int64_t> rank(d.n_terms, -1);
+  for (size_t i = 0; i < vterms.size(); ++i) rank[vterms[i]] = (int64_t)i;
+  std::vector<uint64_t> keys(ps.n_uniq_slots);
+  fetch(keys.data(), ps.uniq.p, keys.size() * 8);
+  const uint64_t tm = (1ull << ps.bits_term) - 1;
+  for (size_t i = 0; i < keys.size(); ++i) {
+    if (i && keys[i] == keys[i - 1]) continue;
+    const uint32_t pidx = (uint32_t)(keys[i] >> (2 * ps.bits_term));
+    const uint64_t s = (keys[i] >> ps.bits_term) & tm, o = keys[i] & tm;
+    if (pidx == ps.type_pidx || (flags[o] & 1)) continue;
+    es->push_back(rank[s]);
+    ed->push_back(rank[o]);
+    ep->push_back(ps.pred_terms[pidx]);
+  }
+}
+
+int dx_instance_graph_sizes(dx_ctx* ctx, int64_t* n_vertices, int64_t* n_edges) {
+  return guard(ctx, [&] {
+    if (!ctx->part.valid) throw DxError(DX_E_INVAL, "no partition run");
+    *n_vertices = (int64_t)ctx->part.stats.n_vertices;
+    *n_edges = (int64_t)ctx->part.stats.n_edges;
+  });
+}
+
+int dx_instance_graph_fetch(dx_ctx* ctx, int64_t* vertex_terms, int64_t* edge_src, int64_t* edge_dst, int64_t* edge_pred) {
+  return guard(ctx, [&] {
+    std::vector<int64_t> v, es, ed, ep;
+    instance_graph(ctx, v, &es, &ed, &ep);
+    memcpy(vertex_terms, v.data(), v.size() * 8);
+    memcpy(edge_src, es.data(), es.size() * 8);
+    memcpy(edge_dst, ed.data(), ed.size() * 8);
+    memcpy(edge_pred, ep.data(), ep.size() * 8);
+  });
+}
+
+// ---- on-disk layout -----------------------------------------------------------------------------------
+int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
+  return guard(ctx, [&] {
+    const PartitionState& ps = ctx->part;
+    const Dictionary& d = ctx->dict;
+    if (!ps.valid || !dataset) throw DxError(DX_E_INVAL, "no partition run / null dataset");
+    const std::string B = norm_base(base), D = dataset, N = std::to_string(ps.n_partitions);
+    std::string L = local_dir ? local_dir : "";
+    if (!L.empty() && L.back() != '/') L += '/';
+    const std::string clusters = B + D + "_data/cluster/clusters_" + N + "_bal";
+    struct stat stt;
+    if (stat(clusters.c_str(), &stt) == 0)  // DAP.scala:86: the stage is skipped when its output exists
+      throw DxError(DX_E_INVAL, clusters + " already exists (the reference skips the stage in that case; remove it to rewrite)");
+    mkdirs(clusters);
+    // dictionary
+    const std::string dd = B + D + "_data/dx_dictionary";
+    mkdirs(dd);
+    {
+      std::vector<uint64_t> off(d.n_terms + 1);
+      fetch(off.data(), d.pool_off.p, off.size() * 8);
+      std::vector<uint8_t> pool(off[d.n_terms]);
+      fetch(pool.data(), d.pool.p, pool.size());
+      std::ofstream f1(dd + "/offsets.bin", std::ios::binary), f2(dd + "/terms.bin", std::ios::binary);
+      f1.write((const char*)off.data(), (std::streamsize)(off.size() * 8));
+      f2.write((const char*)pool.data(), (std::streamsize)pool.size());
+      if (!f1 || !f2) throw DxError(DX_E_IO, "writing dictionary failed");
+    }
+    // first-level partitions + statistics.txt_N (DAP.scala:364-381)
+    mkdirs(L + D + "_local");
+    std::ofstream stats(L + D + "_local/statistics.txt_" + N);
+    std::vector<int64_t> hs, ho, hp;
+    for (int q = 0; q < ps.n_partitions; ++q) {
+      const uint64_t n = ps.part_base[q + 1] - ps.part_base[q];
+      if (!n) continue;  // Spark writes no part file for an empty partition
+      hs.resize(n); ho.resize(n); hp.resize(n);
+      fetch(hs.data(), ps.row_s.p + ps.part_base[q], n * 8);
+      fetch(ho.data(), ps.row_o.p + ps.part_base[q], n * 8);
+      std::vector<uint32_t> pi(n);
+      fetch(pi.data(), ps.row_p.p + ps.part_base[q], n * 4);
+      for (uint64_t i = 0; i < n; ++i) hp[i] = ps.pred_terms[pi[i]];
+      write_cols(clusters + "/part-" + part_name(q) + "-dx-c000.dxcol", n, {hs.data(), ho.data(), hp.data()});
+      const std::string qs = std::to_string(q);
+      stats << (qs.size() == 1 ? "0" + qs : qs) << " " << n << "\n";
+    }
+    touch(clusters + "/_SUCCESS");
+    // VP directories (DAP.scala:419-437) and partition_stat (DAP.scala:101-114)
+    std::map<std::string, uint64_t> dir_rows;
+    std::map<std::string, int> file_no;
+    for (const VpTable& t : ps.tables) {
+      if (!t.in_layout) continue;
+      const std::string pdir = clusters + "/" + part_name(t.partition);
+      const std::string dir = pdir + "/_3=" + ps.pred_storage[t.pidx];
+      mkdirs(dir);
+      hs.resize(t.rows); ho.resize(t.rows);
+      fetch(hs.data(), ps.row_s.p + t.begin, t.rows * 8);
+      fetch(ho.data(), ps.row_o.p + t.begin, t.rows * 8);
+      const int k = file_no[dir]++;
+      write_cols(dir + "/part-" + part_name(k) + "-dx.c000.dxcol", t.rows, {hs.data(), ho.data()});
+      dir_rows[part_name(t.partition)] += t.rows;
+      touch(pdir + "/_SUCCESS");
+    }
+    {
+      std::ofstream pstat(L + D + "_local/partition_stat.txt_" + N + "_bal");
+      for (auto& kv : dir_rows) pstat << kv.first << " " << kv.second << "\n";  // `hdfs dfs -ls` lists by name
+      for (int q = 0; q < ps.n_partitions; ++q) {
+        const uint64_t n = ps.part_base[q + 1] - ps.part_base[q];
+        if (n) pstat << "part-" << part_name(q) << "-dx-c000.dxcol " << n << "\n";
+      }
+    }
+    // statTables.txt: rows per VP table, the input QueryOptimizer.scala:270-276 reads (the reference has no writer for it)
+    {
+      std::ofstream st(L + D + "_local/statTables.txt");
+      std::map<std::string, uint64_t> rows;
+      for (const VpTable& t : ps.tables)
+        if (t.in_layout) rows[part_name(t.partition) + "-_3=" + ps.pred_storage[t.pidx]] += t.rows;
+      for (auto& kv : rows) st << kv.first << " " << kv.second << "\n";
+    }
+    // node index (DAP.scala:402-412)
+    {
+      const std::string ni = B + D + "_data/node_index_" + N;
+      mkdirs(ni);
+      hs.resize(ps.n_node); ho.resize(ps.n_node);
+      fetch(hs.data(), ps.node_s.p, ps.n_node * 8);
+      fetch(ho.data(), ps.node_o.p, ps.n_node * 8);
+      write_cols(ni + "/part-00000-dx.c000.dxcol", ps.n_node, {hs.data(), ho.data()});
+      touch(ni + "/_SUCCESS");
+    }
+    // VP index (DAP.scala:450-501)
+    for (int q = 0; q < ps.n_partitions; ++q) {
+      if (ps.part_base[q + 1] == ps.part_base[q]) continue;
+      const uint64_t n = ps.vpi_base[q + 1] - ps.vpi_base[q];
+      std::vector<int64_t> u(n), pr(n), rl(n);
+      std::vector<int32_t> r32(n);
+      if (n) {
+        int rc = dx_vp_index_fetch(ctx, q, u.data(), r32.data(), pr.data());
+        if (rc) throw DxError(rc, ctx->err);
+      }
+      for (uint64_t i = 0; i < n; ++i) rl[i] = r32[i];
+      const std::string dir = B + D + "_data/classSubPart_index_" + N + "__" + part_name(q);
+      mkdirs(dir);
+      write_cols(dir + "/part-00000-dx.c000.dxcol", n, {u.data(), rl.data(), pr.data()});
+      touch(dir + "/_SUCCESS");
+    }
+  });
+}
+
+int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions) {
+  return guard(ctx, [&] {
+    if (!dataset) throw DxError(DX_E_INVAL, "null dataset");
+    const std::string B = norm_base(base), D = dataset;
+    const std::string dd = B + D + "_data/dx_dictionary";
+    const std::string offs = read_file(dd + "/offsets.bin"), terms = read_file(dd + "/terms.bin");
+    if (offs.size() < 8 || offs.size() % 8) throw DxError(DX_E_IO, "corrupt dictionary offsets");
+    ctx->catalog.clear();
+    ctx->part = PartitionState();
+    Dictionary nd;
+    nd.n_terms = offs.size() / 8 - 1;
+    nd.seed = 0x243F6A8885A308D3ull;
+    nd.pool_off = DevBuf<uint64_t>(ctx->pool, nd.n_terms + 1);
+    nd.pool = DevBuf<uint8_t>(ctx->pool, terms.size() + 16);
+    DX_HIP(hipMemcpy(nd.pool_off.p, offs.data(), offs.size(), hipMemcpyHostToDevice));
+    if (!terms.empty()) DX_HIP(hipMemcpy(nd.pool.p, terms.data(), terms.size(), hipMemcpyHostToDevice));
+    ctx->dict = std::move(nd);
+    dict_build_table(ctx);
+    ctx->ds_base = B;
+    ctx->ds_name = D;
+    ctx->ds_partitions = n_partitions;
+  });
+}
+
+static void load_from_disk(dx_ctx* ctx, const std::string& key, CatalogTable& t) {
+  // QueryProcessor.loadDataset (QueryProcessor.scala:308-325): <hdfs><dataset>_data/cluster/clusters_<N>_bal/<partition>/<sub>/*
+  if (ctx->ds_name.empty()) throw DxError(DX_E_NOENT, "table " + key + " is not resident and no dataset is open");
+  std::string rel = key;
+  const size_t dash = key.find('-');
+  if (dash != std::string::npos) rel = key.substr(0, dash) + "/" + key.substr(dash + 1);
+  const std::string dir = ctx->ds_base + ctx->ds_name + "_data/cluster/clusters_" + std::to_string(ctx->ds_partitions) + "_bal/" + rel;
+  DIR* dp = opendir(dir.c_str());
+  if (!dp) throw DxError(DX_E_NOENT, "cannot open " + dir);
+  std::vector<std::string> files;
+  while (dirent* e = readdir(dp)) {
+    const std::string n = e->d_name;
+    if (n.size() > 6 && n.substr(n.size() - 6) == ".dxcol") files.push_back(dir + "/" + n);
+  }
+  closedir(dp);
+  std::sort(files.begin(), files.end());
+  std::vector<std::string> blobs;
+  uint64_t rows = 0;
+  for (auto& f : files) {
+    blobs.push_back(read_file(f));
+    const std::string& b = blobs.back();
+    if (b.size() < sizeof(ColHeader)) throw DxError(DX_E_IO, "corrupt " + f);
+    ColHeader h;
+    memcpy(&h, b.data(), sizeof h);
+    if (memcmp(h.magic, kMagic, 8) || h.ncols < 2 || b.size() != sizeof h + h.rows * h.ncols * 8) throw DxError(DX_E_IO, "corrupt " + f);
+    rows += h.rows;
+  }
+  t.own_s = DevBuf<int64_t>(ctx->pool, rows);
+  t.own_o = DevBuf<int64_t>(ctx->pool, rows);
+  uint64_t at = 0;
+  for (auto& b : blobs) {
+    ColHeader h;
+    memcpy(&h, b.data(), sizeof h);
+    if (h.rows) {
+      DX_HIP(hipMemcpy(t.own_s.p + at, b.data() + sizeof h, h.rows * 8, hipMemcpyHostToDevice));
+      DX_HIP(hipMemcpy(t.own_o.p + at, b.data() + sizeof h + h.rows * 8, h.rows * 8, hipMemcpyHostToDevice));
+    }
+    at += h.rows;
+  }
+  t.rows = rows;
+  t.s = t.own_s.p;
+  t.o = t.own_o.p;
+}
+
+int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
+  return guard(ctx, [&] {
+    if (!partition_key) throw DxError(DX_E_INVAL, "null key");
+    std::string key = partition_key;
+    const std::string view = view_name(key);
+    auto it = ctx->catalog.find(view);
+    if (it == ctx->catalog.end()) {
+      CatalogTable t;
+      t.key = key;
+      t.view = view;
+      bool resident = false;
+      const PartitionState& ps = ctx->part;
+      if (ps.valid) {
+        const size_t dash = key.find('-');
+        const std::string pn = key.substr(0, dash), sub = dash == std::string::npos ? "" : key.substr(dash + 1);
+        for (const VpTable& vt : ps.tables) {
+          if (!vt.in_layout || part_name(vt.partition) != pn || "_3=" + ps.pred_storage[vt.pidx] != sub) continue;
+          t.slices.push_back({ps.row_s.p + vt.begin, ps.row_o.p + vt.begin, vt.rows});
+          resident = true;
+        }
+      }
+      if (resident) {
+        if (t.slices.size() == 1) {
+          t.s = t.slices[0].s; t.o = t.slices[0].o; t.rows = t.slices[0].rows;
+        } else {  // predicates whose names sanitise alike share one directory: the view is their concatenation
+          for (auto& sl : t.slices) t.rows += sl.rows;
+          t.own_s = DevBuf<int64_t>(ctx->pool, t.rows);
+          t.own_o = DevBuf<int64_t>(ctx->pool, t.rows);
+          uint64_t at = 0;
+          for (auto& sl : t.slices) {
+            DX_HIP(hipMemcpy(t.own_s.p + at, sl.s, sl.rows * 8, hipMemcpyDeviceToDevice));
+            DX_HIP(hipMemcpy(t.own_o.p + at, sl.o, sl.rows * 8, hipMemcpyDeviceToDevice));
+            at += sl.rows;
+          }
+          t.s = t.own_s.p; t.o = t.own_o.p;
+        }
+      } else {
+        load_from_disk(ctx, key, t);
+      }
+      it = ctx->catalog.emplace(view, std::move(t)).first;
+      it->second.s = it->second.own_s.p ? it->second.own_s.p : it->second.s;
+      it->second.o = it->second.own_o.p ? it->second.own_o.p : it->second.o;
+    }
+    if (rows) *rows = it->second.rows;
+  });
+}
+
+int dx_unload_all(dx_ctx* ctx) {
+  return guard(ctx, [&] { ctx->catalog.clear(); });
+}
+
+// ---- queries -----------------------------------------------------------------------------------------
+int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out) {
+  return guard(ctx, [&] {
+    if (!sql || !out) throw DxError(DX_E_INVAL, "null argument");
+    if (mode != DX_QUERY_COUNT && mode != DX_QUERY_BINDINGS) throw DxError(DX_E_INVAL, "unknown query mode");
+    *out = run_query(ctx, sql, mode);
+  });
+}
+
+uint64_t dx_result_count(dx_result* r) { return r ? r->count : 0; }
+int dx_result_columns(dx_result* r) { return r ? (int)r->names.size() : 0; }
+const char* dx_result_column_name(dx_result* r, int i) { return (r && i >= 0 && i < (int)r->names.size()) ? r->names[i].c_str() : ""; }
+double dx_result_device_ms(dx_result* r) { return r ? r->device_ms : 0; }
+
+int dx_result_fetch_ids(dx_result* r, int64_t* ids, int sorted) {
+  if (!r) return DX_E_INVAL;
+  return guard(r->ctx, [&] {
+    if (!r->has_bindings) throw DxError(DX_E_INVAL, "result was computed with DX_QUERY_COUNT: no bindings to fetch");
+    const uint64_t n = r->count;
+    const size_t nc = r->cols.size();
+    for (size_t c = 0; c < nc; ++c) fetch(ids + c * n, r->cols[c].p, n * 8);
+    if (!sorted || n < 2) return;
+    // sort rows by the decoded strings of the columns taken in column-name order
+    dx_ctx* ctx = r->ctx;
+    const Dictionary& d = ctx->dict;
+    std::vector<uint64_t> off(d.n_terms + 1);
+    fetch(off.data(), d.pool_off.p, off.size() * 8);
+    std::vector<uint8_t> pool(off[d.n_terms]);
+    fetch(pool.data(), d.pool.p, pool.size());
+    std::vector<size_t> corder(nc);
+    for (size_t c = 0; c < nc; ++c) corder[c] = c;
+    std::sort(corder.begin(), corder.end(), [&](size_t a, size_t b) { return r->names[a] < r->names[b]; });
+    auto term = [&](int64_t id, const uint8_t*& p, size_t& len) {
+      if (id >= 0) { p = pool.data() + off[id]; len = off[id + 1] - off[id]; }
+      else { const std::string& s = r->virtual_terms[(size_t)(-id - 2)]; p = (const uint8_t*)s.data(); len = s.size(); }
+    };
+    std::vector<uint64_t> perm(n);
+    for (uint64_t i = 0; i < n; ++i) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](uint64_t a, uint64_t b) {
+      for (size_t c : corder) {
+        const int64_t x = ids[c * n + a], y = ids[c * n + b];
+        if (x == y) continue;
+        const uint8_t *px, *py; size_t lx, ly;
+        term(x, px, lx); term(y, py, ly);
+        const int cmp = memcmp(px, py, std::min(lx, ly));
+        if (cmp) return cmp < 0;
+        if (lx != ly) return lx < ly;
+      }
+      return false;
+    });
+    std::vector<int64_t> tmp(n);
+    for (size_t c = 0; c < nc; ++c) {
+      for (uint64_t i = 0; i < n; ++i) tmp[i] = ids[c * n + perm[i]];
+      memcpy(ids + c * n, tmp.data(), n * 8);
+    }
+  });
+}
+
+const char* dx_result_virtual_term(dx_result* r, int64_t id) {
+  if (!r || id > -2 || (size_t)(-id - 2) >= r->virtual_terms.size()) return nullptr;
+  return r->virtual_terms[(size_t)(-id - 2)].c_str();
+}
+
+void dx_result_free(dx_result* r) { delete r; }
+
+}  // extern "C"

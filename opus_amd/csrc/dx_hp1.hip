@@ -1,0 +1,953 @@
+// Partitioner hot path (post-DAP stage) as HIP kernels for gfx950.
+//
+// What the reference computes with string-keyed Spark shuffles (Preprocessor.scala:116-192,
+// partitioner/DAP.scala:360-509, 567-629) is restated here as integer set algebra:
+//
+//   * every term (subject, predicate, object) gets a dense int64 id through an open-addressing hash
+//     table in HBM (64-bit hash as bucket choice, full byte compare as proof);
+//   * P(C) = bitmask of first-level partitions of class C (class index);
+//     M(v) = OR of P(C) over the types of vertex v; E(v) = v is an endpoint of an object-property triple;
+//   * a distinct input triple (s, p, o) is placed in the partitions of
+//         M(s) | M(o)          if it is an object-property triple        (DAP.scala:575-580)
+//         E(s) ? P(o) : 0      if p is rdf:type                           (DAP.scala:583-593)
+//         E(s) ? M(s) : 0      if o is a literal                          (DAP.scala:595-602)
+//     which is the closed form of the reference's three triplet streams: each of them iterates over
+//     edges, so a vertex contributes only if it has an edge, type triples go to the partitions of
+//     their own class, label triples to the partitions of all classes of their subject;
+//   * sorting the distinct triples by (predicate, s, o) once and splitting them stably by partition
+//     bit yields every vertical-partition table as a contiguous, sorted slice.
+#include <algorithm>
+#include <chrono>
+
+#include "dx_device.h"
+#include "dx_state.h"
+
+namespace dx {
+
+namespace {
+
+constexpr uint8_t kFlagLiteral = 1, kFlagVertex = 2, kFlagEdge = 4, kFlagNode = 8;
+constexpr int kTypeLen = 49;
+__constant__ char c_rdf_type[kTypeLen + 1] = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>";
+
+__device__ __forceinline__ bool is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
+__device__ __forceinline__ bool is_jws(uint8_t c) { return c == ' ' || c == '\t' || c == 0x0B || c == 0x0C; }
+
+// ---- 1. record starts -----------------------------------------------------------------------------
+// A line starts at byte 0 and after every terminator (LF, CR LF, or a lone CR: Hadoop's LineRecordReader
+// behind sc.textFile); a record is a line that does not start with '#' (Preprocessor.scala:120).
+constexpr int LS_THREADS = 256;
+constexpr int LS_ITERS = 8;
+constexpr int LS_TILE = LS_THREADS * 16 * LS_ITERS;  // 32 KiB of text per block
+
+template <bool WRITE>
+__global__ void __launch_bounds__(LS_THREADS)
+k_line_starts(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ tile_counts,
+              uint64_t* __restrict__ rec_off, unsigned long long* __restrict__ err) {
+  __shared__ uint32_t lds[8];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
+  uint32_t run = WRITE ? tile_counts[blockIdx.x] : 0;  // exclusive prefix when writing
+  uint32_t mine = 0;
+  for (int it = 0; it < LS_ITERS; ++it) {
+    const uint64_t i0 = tile0 + (uint64_t)it * (LS_THREADS * 16) + (uint64_t)threadIdx.x * 16;
+    uint8_t c[16];
+    uint32_t mask = 0;
+    if (i0 < n) {
+      if (i0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[j] = (uint8_t)(w[j >> 2] >> ((j & 3) * 8));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[j] = (i0 + j < n) ? text[i0 + j] : (uint8_t)'x';
+      }
+      uint8_t prev = i0 ? text[i0 - 1] : (uint8_t)'\n';
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint8_t cur = c[j];
+        const bool start = (i0 + j < n) && (prev == '\n' || (prev == '\r' && cur != '\n'));
+        if (start) {
+          if (is_eol(cur)) atomicMin(err, (unsigned long long)(i0 + j));  // empty line: the reference throws
+          else if (cur != '#') mask |= 1u << j;
+        }
+        prev = cur;
+      }
+    }
+    const uint32_t cnt = __popc(mask);
+    if (!WRITE) {
+      mine += cnt;
+    } else {
+      uint32_t total;
+      uint32_t pos = run + block_excl_scan_256<uint32_t>(cnt, lds, total);
+      while (mask) {
+        const int j = __ffs(mask) - 1;
+        mask &= mask - 1;
+        rec_off[pos++] = i0 + j;
+      }
+      run += total;
+    }
+  }
+  if (!WRITE) {
+    uint32_t total;
+    (void)block_excl_scan_256<uint32_t>(mine, lds, total);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+  }
+}
+
+// ---- 2. tokenise + hash -------------------------------------------------------------------------------
+// One record per thread. Field split = java.lang.String.split("\\s+", 3) (Preprocessor.scala:121);
+// subject/predicate are trimmed; the object is the third field minus its last two UTF-16 units,
+// trimmed (:122). Lines with fewer than three fields make the reference throw: reported through err.
+__device__ __forceinline__ void trim_range(const uint8_t* t, uint64_t& b, uint64_t& e) {
+  while (b < e && t[b] <= 0x20) ++b;
+  while (e > b && t[e - 1] <= 0x20) --e;
+}
+__device__ __forceinline__ uint64_t hash_range(const uint8_t* t, uint64_t b, uint64_t e, uint64_t seed) {
+  TermHash h(seed);
+  for (uint64_t i = b; i < e; ++i) h.add(t[i]);
+  return h.finish((uint32_t)(e - b));
+}
+
+__global__ void __launch_bounds__(256)
+k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+           uint64_t seed, uint64_t* __restrict__ t_rep /*3*n_rec packed (off,len)*/, uint64_t* __restrict__ t_hash,
+           uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rec) return;
+  const uint64_t start = rec_off[r];
+  uint64_t p = start;
+  uint64_t b[3], e[3];
+  bool bad = false;
+  b[0] = p;
+  while (p < n && !is_eol(text[p]) && !is_jws(text[p])) ++p;
+  e[0] = p;
+  if (p >= n || is_eol(text[p])) bad = true;
+  if (!bad) {
+    while (p < n && is_jws(text[p])) ++p;
+    b[1] = p;
+    while (p < n && !is_eol(text[p]) && !is_jws(text[p])) ++p;
+    e[1] = p;
+    if (p >= n || is_eol(text[p])) bad = true;
+  }
+  if (bad) {
+    atomicMin(err, (unsigned long long)start);
+    for (int k = 0; k < 3; ++k) { t_rep[3ull * r + k] = 0; t_hash[3ull * r + k] = 1; }
+    kind[r] = 0;
+    return;
+  }
+  while (p < n && is_jws(text[p])) ++p;
+  b[2] = p;
+  while (p < n && !is_eol(text[p])) ++p;
+  e[2] = p;
+  // dropRight(2): two UTF-16 code units from the end (a 4-byte UTF-8 sequence is two units)
+  int units = 2;
+  while (units > 0 && e[2] > b[2]) {
+    uint64_t q = e[2] - 1;
+    while (q > b[2] && (text[q] & 0xC0) == 0x80) --q;
+    const int u = ((text[q] & 0xF8) == 0xF0) ? 2 : 1;
+    if (u > units) { atomicMin(err, (unsigned long long)start); break; }  // would split a surrogate pair
+    units -= u;
+    e[2] = q;
+  }
+  for (int k = 0; k < 3; ++k) trim_range(text, b[k], e[k]);
+  bool too_long = false;
+  for (int k = 0; k < 3; ++k) {
+    const uint64_t len = e[k] - b[k];
+    if (len >= (1ull << kRepLenBits) || b[k] >= (1ull << (64 - kRepLenBits))) too_long = true;
+    t_rep[3ull * r + k] = (b[k] << kRepLenBits) | (len & ((1ull << kRepLenBits) - 1));
+    t_hash[3ull * r + k] = hash_range(text, b[k], e[k], seed);
+  }
+  if (too_long) atomicMin(err, (unsigned long long)start);
+  uint8_t kd = 0;
+  if (e[1] - b[1] == kTypeLen) {
+    bool eq = true;
+    for (int i = 0; i < kTypeLen; ++i) eq &= (text[b[1] + i] == (uint8_t)c_rdf_type[i]);
+    if (eq) kd = 1;
+  }
+  if (kd == 0 && e[2] > b[2] && text[b[2]] == '"') kd = 2;
+  kind[r] = kd;
+}
+
+// ---- 3. dictionary ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dict_find_or_claim(uint64_t* keys, uint64_t mask, uint64_t h) {
+  uint64_t slot = h & mask;
+  for (;;) {
+    uint64_t cur = keys[slot];
+    if (cur == h) break;
+    if (cur == 0) {
+      cur = atomicCAS((unsigned long long*)&keys[slot], 0ull, (unsigned long long)h);
+      if (cur == 0 || cur == h) break;
+    }
+    slot = (slot + 1) & mask;
+  }
+  return (uint32_t)slot;
+}
+
+// Every occurrence claims / finds the slot of its hash and lowers the slot's representative to the
+// smallest (offset, length) word, i.e. the first occurrence in the text: ids do not depend on timing.
+__global__ void __launch_bounds__(256)
+k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ t_rep, uint64_t n_occ,
+              uint64_t* __restrict__ keys, uint64_t* __restrict__ rep, uint64_t mask, uint32_t* __restrict__ t_slot) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_occ) return;
+  const uint32_t slot = dict_find_or_claim(keys, mask, t_hash[i]);
+  const uint64_t mine = t_rep[i];
+  if (rep[slot] > mine) atomicMin((unsigned long long*)&rep[slot], (unsigned long long)mine);
+  t_slot[i] = slot;
+}
+
+// first[i] = 1 when occurrence i is its slot's representative; any occurrence whose bytes differ from
+// the representative's proves a 64-bit collision between different strings.
+__global__ void __launch_bounds__(256)
+k_dict_verify(const uint8_t* __restrict__ text, const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot,
+              uint64_t n_occ, const uint64_t* __restrict__ rep, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_occ) return;
+  const uint64_t mine = t_rep[i], r = rep[t_slot[i]];
+  if (mine == r) { first[i] = 1; return; }
+  first[i] = 0;
+  const uint64_t lm = mine & ((1ull << kRepLenBits) - 1), lr = r & ((1ull << kRepLenBits) - 1);
+  bool same = lm == lr;
+  if (same) {
+    const uint8_t* a = text + (mine >> kRepLenBits);
+    const uint8_t* b = text + (r >> kRepLenBits);
+    for (uint64_t j = 0; j < lm; ++j)
+      if (a[j] != b[j]) { same = false; break; }
+  }
+  if (!same) *collision = 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_dict_assign(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot, const uint8_t* __restrict__ first,
+              const uint32_t* __restrict__ first_scan, uint64_t n_occ, uint32_t* __restrict__ slot_id,
+              uint32_t* __restrict__ term_len, uint64_t* __restrict__ term_src) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_occ || !first[i]) return;
+  const uint32_t id = first_scan[i];
+  slot_id[t_slot[i]] = id;
+  term_len[id] = (uint32_t)(t_rep[i] & ((1ull << kRepLenBits) - 1));
+  term_src[id] = t_rep[i] >> kRepLenBits;
+}
+
+// Encoded records (s, p, o as term ids) + per-term flags that follow from the record kinds.
+__global__ void __launch_bounds__(256)
+k_encode(const uint32_t* __restrict__ t_slot, const uint32_t* __restrict__ slot_id, const uint8_t* __restrict__ kind,
+         uint32_t n_rec, uint32_t* __restrict__ S, uint32_t* __restrict__ P, uint32_t* __restrict__ O,
+         uint8_t* __restrict__ term_flags, uint8_t* __restrict__ is_pred) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rec) return;
+  const uint32_t s = slot_id[t_slot[3ull * r]], p = slot_id[t_slot[3ull * r + 1]], o = slot_id[t_slot[3ull * r + 2]];
+  S[r] = s; P[r] = p; O[r] = o;
+  is_pred[p] = 1;
+  const uint8_t k = kind[r];
+  // benign races: concurrent writers OR constant bits into a byte through atomicOr on the containing word
+  auto set_flag = [&](uint32_t id, uint8_t f) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(term_flags) + (id >> 2);
+    const uint32_t bit = (uint32_t)f << ((id & 3) * 8);
+    if ((*w & bit) != bit) atomicOr(w, bit);
+  };
+  if (k == 0) { set_flag(s, kFlagVertex | kFlagEdge); set_flag(o, kFlagVertex | kFlagEdge); }
+  else { set_flag(s, kFlagVertex); if (k == 2) set_flag(o, kFlagLiteral); }
+}
+
+// Copies term bytes from the input text into the id-ordered pool.
+__global__ void __launch_bounds__(256)
+k_pool_copy(const uint8_t* __restrict__ text, const uint64_t* __restrict__ term_src, const uint64_t* __restrict__ pool_off,
+            uint64_t n_terms, uint8_t* __restrict__ pool) {
+  // one wave per term: 64 lanes stride over the bytes
+  const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (t >= n_terms) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t b = pool_off[t], len = pool_off[t + 1] - b;
+  const uint8_t* src = text + term_src[t];
+  for (uint64_t j = lane; j < len; j += 64) pool[b + j] = src[j];
+}
+
+// Looks strings up: hash, probe, byte-compare against the pool.
+__global__ void __launch_bounds__(64)
+k_lookup(const uint8_t* __restrict__ q, const uint64_t* __restrict__ q_off, uint32_t nq, uint64_t seed,
+         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, uint64_t mask,
+         const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t b = q_off[i], e = q_off[i + 1];
+  const uint64_t h = hash_range(q, b, e, seed);
+  uint64_t slot = h & mask;
+  int64_t res = -1;
+  for (;;) {
+    const uint64_t cur = keys[slot];
+    if (cur == 0) break;
+    if (cur == h) {
+      const uint32_t id = ids[slot];
+      const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
+      bool same = pl == e - b;
+      for (uint64_t j = 0; same && j < pl; ++j) same = pool[pb + j] == q[b + j];
+      if (same) res = id;
+      break;  // one slot per hash: a different string with this hash is not in the dictionary
+    }
+    slot = (slot + 1) & mask;
+  }
+  out[i] = res;
+}
+
+// Rebuilds the lookup table from the pool (dictionary loaded from disk).
+__global__ void __launch_bounds__(256)
+k_table_from_pool(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, uint64_t n_terms, uint64_t seed,
+                  uint64_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t mask, uint32_t* __restrict__ collision) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  const uint64_t h = hash_range(pool, pool_off[t], pool_off[t + 1], seed);
+  uint64_t slot = h & mask;
+  for (;;) {
+    const uint64_t cur = atomicCAS((unsigned long long*)&keys[slot], 0ull, (unsigned long long)h);
+    if (cur == 0) { ids[slot] = (uint32_t)t; break; }
+    if (cur == h) { *collision = 1; break; }  // two pool strings are distinct by construction
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ---- 4. class masks, vertex masks -----------------------------------------------------------------------
+__global__ void k_set_class_masks(const int64_t* __restrict__ ids, const uint64_t* __restrict__ masks, uint32_t n,
+                                  uint64_t* __restrict__ Pm) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ids[i] >= 0) atomicOr((unsigned long long*)&Pm[ids[i]], (unsigned long long)masks[i]);
+}
+
+__global__ void __launch_bounds__(256)
+k_vertex_masks(const uint32_t* __restrict__ S, const uint32_t* __restrict__ O, const uint8_t* __restrict__ kind, uint32_t n_rec,
+               const uint64_t* __restrict__ Pm, uint64_t* __restrict__ M) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rec || kind[r] != 1) return;
+  const uint64_t m = Pm[O[r]];
+  if (m && (M[S[r]] & m) != m) atomicOr((unsigned long long*)&M[S[r]], (unsigned long long)m);
+}
+
+// ---- 5. sort keys, placement masks -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pack_keys(const uint32_t* __restrict__ S, const uint32_t* __restrict__ P, const uint32_t* __restrict__ O, uint32_t n_rec,
+            const uint32_t* __restrict__ pred_index, int bits_term, uint64_t* __restrict__ keys) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rec) return;
+  keys[r] = ((uint64_t)pred_index[P[r]] << (2 * bits_term)) | ((uint64_t)S[r] << bits_term) | (uint64_t)O[r];
+}
+
+struct Unpacked { uint32_t pidx, s, o; };
+__device__ __forceinline__ Unpacked unpack(uint64_t k, int bits_term) {
+  const uint64_t tm = (1ull << bits_term) - 1;
+  return {(uint32_t)(k >> (2 * bits_term)), (uint32_t)((k >> bits_term) & tm), (uint32_t)(k & tm)};
+}
+
+// mask[i] = partitions of sorted triple i (0 for a duplicate of its predecessor); also counts
+// distinct triples, distinct edges and node-index rows.
+__global__ void __launch_bounds__(256)
+k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+        const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, uint64_t* __restrict__ mask,
+        uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges*/) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t uq = 0, ed = 0;
+  if (i < n) {
+    const uint64_t k = keys[i];
+    uint64_t m = 0;
+    uint8_t nf = 0;
+    if (i == 0 || keys[i - 1] != k) {
+      uq = 1;
+      const Unpacked t = unpack(k, bits_term);
+      if (t.pidx == type_pidx) {
+        m = (flags[t.s] & kFlagEdge) ? Pm[t.o] : 0;
+        nf = m != 0;
+      } else if (flags[t.o] & kFlagLiteral) {
+        m = (flags[t.s] & kFlagEdge) ? M[t.s] : 0;
+      } else {
+        ed = 1;
+        m = M[t.s] | M[t.o];
+      }
+    }
+    mask[i] = m;
+    node_flag[i] = nf;
+  }
+  uq = wave_reduce_u32(uq);
+  ed = wave_reduce_u32(ed);
+  if ((threadIdx.x & 63) == 0) {
+    if (uq) atomicAdd(&counters[0], (unsigned long long)uq);
+    if (ed) atomicAdd(&counters[1], (unsigned long long)ed);
+  }
+}
+
+// ---- 6. stable split by partition bit -----------------------------------------------------------------------
+// counts[q][tile] = triples of the tile placed in partition q; after the scan of that matrix the
+// scatter writes row i of partition q at counts[q][tile] + (rank of i among the tile's rows with bit q).
+constexpr int SP_THREADS = 256;
+constexpr int SP_TILE = 2048;  // each wave owns 512 consecutive triples
+
+__global__ void __launch_bounds__(SP_THREADS)
+k_split_count(const uint64_t* __restrict__ mask, uint32_t n, int nparts, uint32_t* __restrict__ counts, unsigned ntiles) {
+  __shared__ uint32_t c[DX_MAX_PARTITIONS];
+  if (threadIdx.x < DX_MAX_PARTITIONS) c[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * SP_TILE;
+  for (int j = 0; j < SP_TILE / SP_THREADS; ++j) {
+    const uint32_t i = base + j * SP_THREADS + threadIdx.x;
+    const uint64_t m = i < n ? mask[i] : 0;
+    for (int q = 0; q < nparts; ++q) {
+      const uint64_t b = __ballot((m >> q) & 1);
+      if ((threadIdx.x & 63) == 0 && b) atomicAdd(&c[q], (uint32_t)__popcll(b));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nparts) counts[(size_t)threadIdx.x * ntiles + blockIdx.x] = c[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SP_THREADS)
+k_split_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ mask, uint32_t n, int nparts, int bits_term,
+                const uint32_t* __restrict__ offs, unsigned ntiles, int64_t* __restrict__ row_s, int64_t* __restrict__ row_o,
+                uint32_t* __restrict__ row_p) {
+  __shared__ uint32_t wcnt[4][DX_MAX_PARTITIONS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t wbase = blockIdx.x * SP_TILE + w * (SP_TILE / 4);
+  // pass 1: per-wave totals per partition
+  uint32_t tot = 0;  // lane q accumulates partition q (nparts <= 64)
+  for (int j = 0; j < SP_TILE / 4 / 64; ++j) {
+    const uint32_t i = wbase + j * 64 + lane;
+    const uint64_t m = i < n ? mask[i] : 0;
+    for (int q = 0; q < nparts; ++q) {
+      const uint32_t c = (uint32_t)__popcll(__ballot((m >> q) & 1));
+      if (lane == q) tot += c;
+    }
+  }
+  if (lane < DX_MAX_PARTITIONS) wcnt[w][lane] = tot;
+  __syncthreads();
+  if (threadIdx.x < nparts) {
+    uint32_t run = offs[(size_t)threadIdx.x * ntiles + blockIdx.x];
+    for (int i = 0; i < 4; ++i) { const uint32_t c = wcnt[i][threadIdx.x]; wcnt[i][threadIdx.x] = run; run += c; }
+  }
+  __syncthreads();
+  // pass 2: write
+  uint32_t basev = lane < DX_MAX_PARTITIONS ? wcnt[w][lane] : 0;  // lane q holds the running base of partition q
+  for (int j = 0; j < SP_TILE / 4 / 64; ++j) {
+    const uint32_t i = wbase + j * 64 + lane;
+    const uint64_t m = i < n ? mask[i] : 0;
+    Unpacked t{0, 0, 0};
+    if (m) t = unpack(keys[i], bits_term);
+    for (int q = 0; q < nparts; ++q) {
+      const bool bit = (m >> q) & 1;
+      const uint64_t b = __ballot(bit);
+      if (!b) continue;  // wave-uniform
+      const uint32_t qbase = __shfl(basev, q, 64);
+      if (bit) {
+        const uint32_t pos = qbase + (uint32_t)__popcll(b & lt);
+        row_s[pos] = (int64_t)t.s;
+        row_o[pos] = (int64_t)t.o;
+        row_p[pos] = t.pidx;
+      }
+      if (lane == q) basev += (uint32_t)__popcll(b);
+    }
+  }
+}
+
+// table_start[q * np + pidx] = first row of that table (rows are sorted by pidx inside a partition)
+__global__ void __launch_bounds__(256)
+k_table_starts(const uint32_t* __restrict__ row_p, const uint32_t* __restrict__ part_base /*nparts+1*/, int nparts, uint32_t np,
+               uint32_t* __restrict__ start) {
+  const uint32_t total = part_base[nparts];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int q = 0;
+  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+  const uint32_t p = row_p[i];
+  if (i == part_base[q] || row_p[i - 1] != p) start[(size_t)q * np + p] = i;
+}
+
+// ---- 7. node index, VP index ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_node_index(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ node_flag, const uint32_t* __restrict__ pos, uint32_t n,
+             int bits_term, int64_t* __restrict__ ns, int64_t* __restrict__ no, uint8_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !node_flag[i]) return;
+  const Unpacked t = unpack(keys[i], bits_term);
+  ns[pos[i]] = t.s;
+  no[pos[i]] = t.o;
+  uint32_t* w = reinterpret_cast<uint32_t*>(flags) + (t.s >> 2);
+  const uint32_t bit = (uint32_t)kFlagNode << ((t.s & 3) * 8);
+  if (!(*w & bit)) atomicOr(w, bit);
+}
+
+// For each row of each partition, the entries it contributes to the partition's VP index
+// (DAP.scala:479-497): (s, 's', p) when s is a typed uri (has a node-index row), (o, 'o', p) when o is
+// one, and (o, 'o', rdf:type) for every type row. An 's' entry equal to the previous row's is skipped
+// (rows are sorted by (p, s)), the rest of the duplicates fall to the sort.
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_vpi_emit(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
+           const uint32_t* __restrict__ part_base, int nparts, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+           int bits_term, int bits_pred, uint8_t* __restrict__ cnt, const uint32_t* __restrict__ pos, uint64_t* __restrict__ out) {
+  const uint32_t total = part_base[nparts];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int q = 0;
+  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+  const uint32_t s = (uint32_t)row_s[i], o = (uint32_t)row_o[i], p = row_p[i];
+  bool es = (flags[s] & kFlagNode) != 0;
+  if (es && i > part_base[q] && row_p[i - 1] == p && (uint32_t)row_s[i - 1] == s) es = false;
+  const bool eo = (flags[o] & kFlagNode) != 0 || p == type_pidx;
+  if (!WRITE) { cnt[i] = (uint8_t)es + (uint8_t)eo; return; }
+  uint32_t w = pos[i];
+  const uint64_t qq = (uint64_t)q << (bits_term + 1 + bits_pred);
+  if (es) out[w++] = qq | ((uint64_t)s << (1 + bits_pred)) | p;
+  if (eo) out[w++] = qq | ((uint64_t)o << (1 + bits_pred)) | (1ull << bits_pred) | p;
+}
+
+__global__ void __launch_bounds__(256)
+k_flag_distinct(const uint64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+k_compact_u64(const uint64_t* __restrict__ in, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n,
+              uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) out[pos[i]] = in[i];
+}
+// base[q] = first index whose partition field is >= q (keys sorted)
+__global__ void k_vpi_bases(const uint64_t* __restrict__ keys, uint32_t n, int shift, int nparts, uint32_t* __restrict__ base) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > nparts) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((keys[mid] >> shift) < (uint64_t)q) lo = mid + 1; else hi = mid;
+  }
+  base[q] = lo;
+}
+
+int bits_for(uint64_t n) {  // bits needed for values in [0, n)
+  int b = 1;
+  while ((1ull << b) < n) ++b;
+  return b;
+}
+inline unsigned blocks(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per ? (n + per - 1) / per : 1); }
+
+struct StageTimer {
+  hipStream_t s;
+  std::vector<hipEvent_t> ev;
+  explicit StageTimer(hipStream_t st) : s(st) { mark(); }
+  void mark() { hipEvent_t e; DX_HIP(hipEventCreate(&e)); DX_HIP(hipEventRecord(e, s)); ev.push_back(e); }
+  ~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+
+}  // namespace
+
+const char* const kStageNames[12] = {"line_scan", "tokenise_hash", "dictionary", "string_pool", "vertex_masks", "sort_triples",
+                                     "place", "split_partitions", "node_index", "vp_index", "", ""};
+
+void dict_build_table(dx_ctx* ctx) {
+  Dictionary& d = ctx->dict;
+  hipStream_t s = ctx->stream;
+  uint64_t cap = 1024;
+  while (cap < d.n_terms * 2) cap <<= 1;
+  DevBuf<uint32_t> coll(ctx->pool, 1);
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    d.ht_keys = DevBuf<uint64_t>(ctx->pool, cap);
+    d.ht_ids = DevBuf<uint32_t>(ctx->pool, cap);
+    d.ht_mask = cap - 1;
+    DX_HIP(hipMemsetAsync(d.ht_keys.p, 0, cap * 8, s));
+    DX_HIP(hipMemsetAsync(coll.p, 0, 4, s));
+    if (d.n_terms)
+      hipLaunchKernelGGL(k_table_from_pool, dim3(blocks(d.n_terms)), dim3(256), 0, s, d.pool.p, d.pool_off.p, d.n_terms, d.seed,
+                         d.ht_keys.p, d.ht_ids.p, d.ht_mask, coll.p);
+    uint32_t c = 0;
+    DX_HIP(hipMemcpyAsync(&c, coll.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    if (!c) return;
+    d.seed = mix64(d.seed + 0x9E3779B97F4A7C15ull);
+  }
+  throw DxError(DX_E_RANGE, "dictionary: hash collisions persisted over 8 seeds");
+}
+
+void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids_host) {
+  if (n == 0) return;
+  Dictionary& d = ctx->dict;
+  if (!d.valid()) throw DxError(DX_E_INVAL, "no dictionary: run dx_partition_* or dx_open_dataset first");
+  hipStream_t s = ctx->stream;
+  const uint64_t nbytes = offsets[n];
+  DevBuf<uint8_t> q(ctx->pool, nbytes + 1);
+  DevBuf<uint64_t> qo(ctx->pool, n + 1);
+  DevBuf<int64_t> out(ctx->pool, n);
+  DX_HIP(hipMemcpyAsync(q.p, bytes, nbytes, hipMemcpyHostToDevice, s));
+  DX_HIP(hipMemcpyAsync(qo.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_lookup, dim3(blocks(n, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)n, d.seed, d.ht_keys.p, d.ht_ids.p,
+                     d.ht_mask, d.pool.p, d.pool_off.p, out.p);
+  DX_HIP(hipMemcpyAsync(ids_host, out.p, n * 8, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+}
+
+static size_t utf16_units(const std::string& s) {
+  size_t u = 0;
+  for (unsigned char c : s) {
+    if ((c & 0xC0) != 0x80) ++u;
+    if ((c & 0xF8) == 0xF0) ++u;
+  }
+  return u;
+}
+static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514 on UTF-16 units
+  std::string out;
+  for (size_t i = 0; i < s.size();) {
+    unsigned char c = (unsigned char)s[i];
+    if (c < 0x80) {
+      if ((c >= 'A' && c <= 'Z')) out += (char)(c - 'A' + 'a');
+      else if ((c >= 'a' && c <= 'z') || (c >= '0' && c <= '9')) out += (char)c;
+      else out += '_';
+      ++i;
+    } else {
+      const int len = (c & 0xE0) == 0xC0 ? 2 : (c & 0xF0) == 0xE0 ? 3 : (c & 0xF8) == 0xF0 ? 4 : 1;
+      out += (len == 4) ? "__" : "_";  // one '_' per UTF-16 unit
+      i += len;
+    }
+  }
+  return out;
+}
+
+void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
+                   int nparts) {
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  if (nparts < 1 || nparts > DX_MAX_PARTITIONS) throw DxError(DX_E_INVAL, "n_partitions must be in [1, 64]");
+  if (n_bytes >= (1ull << (64 - kRepLenBits))) throw DxError(DX_E_RANGE, "input larger than 1 TiB");
+  ctx->catalog.clear();
+  ctx->part = PartitionState();
+  ctx->dict = Dictionary();
+  PartitionState& ps = ctx->part;
+  ps.n_partitions = nparts;
+  dx_part_stats& st = ps.stats;
+  st.n_bytes = n_bytes;
+  StageTimer tm(s);
+
+  // ---- 1. record starts
+  const unsigned ntiles = (unsigned)((n_bytes + LS_TILE - 1) / LS_TILE);
+  DevBuf<unsigned long long> err(pool, 1);
+  DX_HIP(hipMemsetAsync(err.p, 0xFF, 8, s));
+  DevBuf<uint32_t> tile_counts(pool, ntiles + 1);
+  DevBuf<uint32_t> d_total(pool, 4);
+  uint32_t n_rec = 0;
+  if (n_bytes) {
+    hipLaunchKernelGGL(k_line_starts<false>, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, tile_counts.p, nullptr, err.p);
+    exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, ntiles, d_total.p, s);
+    DX_HIP(hipMemcpyAsync(&n_rec, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+  }
+  st.n_triples = n_rec;
+  DevBuf<uint64_t> rec_off(pool, n_rec);
+  if (n_rec) hipLaunchKernelGGL(k_line_starts<true>, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, tile_counts.p, rec_off.p, err.p);
+  tm.mark();
+
+  const uint64_t n_occ = 3ull * n_rec;
+  if (n_occ >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32/3 records on one GPU");
+  DevBuf<uint64_t> t_rep(pool, n_occ), t_hash(pool, n_occ);
+  DevBuf<uint8_t> kind(pool, n_rec);
+  DevBuf<uint32_t> t_slot(pool, n_occ);
+  uint64_t cap = 1024;
+  while (cap < 4ull * n_rec) cap <<= 1;
+  DevBuf<uint64_t> keys(pool, cap), rep(pool, cap);
+  DevBuf<uint32_t> slot_id(pool, cap);
+  DevBuf<uint8_t> first(pool, n_occ);
+  DevBuf<uint32_t> first_scan(pool, n_occ);
+  DevBuf<uint32_t> coll(pool, 1);
+  uint64_t seed = 0x243F6A8885A308D3ull;
+  uint32_t n_terms = 0;
+  float ms_tok = 0, ms_dict = 0;
+  for (int attempt = 0;; ++attempt) {
+    // ---- 2. tokenise + hash
+    hipEvent_t e0, e1, e2;
+    DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2));
+    DX_HIP(hipEventRecord(e0, s));
+    if (n_rec)
+      hipLaunchKernelGGL(k_tokenise, dim3(blocks(n_rec)), dim3(256), 0, s, text, n_bytes, rec_off.p, n_rec, seed, t_rep.p, t_hash.p,
+                         kind.p, err.p);
+    DX_HIP(hipEventRecord(e1, s));
+    // ---- 3. dictionary
+    DX_HIP(hipMemsetAsync(keys.p, 0, cap * 8, s));
+    DX_HIP(hipMemsetAsync(rep.p, 0xFF, cap * 8, s));
+    DX_HIP(hipMemsetAsync(coll.p, 0, 4, s));
+    if (n_occ) {
+      hipLaunchKernelGGL(k_dict_insert, dim3(blocks(n_occ)), dim3(256), 0, s, t_hash.p, t_rep.p, n_occ, keys.p, rep.p, cap - 1, t_slot.p);
+      hipLaunchKernelGGL(k_dict_verify, dim3(blocks(n_occ)), dim3(256), 0, s, text, t_rep.p, t_slot.p, n_occ, rep.p, first.p, coll.p);
+    }
+    exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
+    DX_HIP(hipEventRecord(e2, s));
+    unsigned long long h_err = ~0ull;
+    uint32_t h_coll = 0;
+    DX_HIP(hipMemcpyAsync(&h_err, err.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(&h_coll, coll.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(&n_terms, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    float a = 0, b = 0;
+    DX_HIP(hipEventElapsedTime(&a, e0, e1)); DX_HIP(hipEventElapsedTime(&b, e1, e2));
+    ms_tok += a; ms_dict += b;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    if (h_err != ~0ull)
+      throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
+                                        " (empty line, fewer than three fields, or a term of 16 MiB or more)");
+    if (!h_coll) break;
+    if (attempt >= 7) throw DxError(DX_E_RANGE, "dictionary: hash collisions persisted over 8 seeds");
+    seed = mix64(seed + 0x9E3779B97F4A7C15ull);
+    ++st.hash_retries;
+  }
+  st.n_terms = n_terms;
+  Dictionary& d = ctx->dict;
+  d.n_terms = n_terms;
+  d.seed = seed;
+  DevBuf<uint32_t> term_len(pool, (size_t)n_terms + 1);
+  DevBuf<uint64_t> term_src(pool, n_terms);
+  DevBuf<uint32_t> S(pool, n_rec), P(pool, n_rec), O(pool, n_rec);
+  ps.term_flags = DevBuf<uint8_t>(pool, ((size_t)n_terms + 4) & ~(size_t)3);
+  DevBuf<uint8_t> is_pred(pool, n_terms);
+  DX_HIP(hipMemsetAsync(ps.term_flags.p, 0, ps.term_flags.bytes(), s));
+  DX_HIP(hipMemsetAsync(is_pred.p, 0, n_terms ? n_terms : 1, s));
+  DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
+  if (n_occ) {
+    hipLaunchKernelGGL(k_dict_assign, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, slot_id.p,
+                       term_len.p, term_src.p);
+    hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_slot.p, slot_id.p, kind.p, n_rec, S.p, P.p, O.p,
+                       ps.term_flags.p, is_pred.p);
+  }
+  // the build-time table doubles as the lookup table
+  d.ht_keys = std::move(keys);
+  d.ht_ids = std::move(slot_id);
+  d.ht_mask = cap - 1;
+  tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
+  t_hash.reset(); t_slot.reset(); first.reset(); first_scan.reset(); rep.reset(); rec_off.reset();
+
+  // ---- 4. string pool
+  d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
+  DevBuf<uint64_t> d_total64(pool, 1);
+  exclusive_scan_u32_u64(pool, term_len.p, d.pool_off.p, (size_t)n_terms + 1, d_total64.p, s);
+  uint64_t pool_bytes = 0;
+  DX_HIP(hipMemcpyAsync(&pool_bytes, d_total64.p, 8, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  d.pool = DevBuf<uint8_t>(pool, pool_bytes + 16);
+  if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks((uint64_t)n_terms * 64)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
+                                  (uint64_t)n_terms, d.pool.p);
+  tm.mark();
+  t_rep.reset(); term_src.reset(); term_len.reset();
+
+  // ---- 5. class masks and vertex masks
+  DevBuf<uint64_t> Pm(pool, n_terms), M(pool, n_terms);
+  DX_HIP(hipMemsetAsync(Pm.p, 0, Pm.bytes() ? Pm.bytes() : 8, s));
+  DX_HIP(hipMemsetAsync(M.p, 0, M.bytes() ? M.bytes() : 8, s));
+  int64_t type_term = -1;
+  {
+    std::string bytes;
+    std::vector<uint64_t> offs{0};
+    std::vector<uint64_t> masks;
+    for (auto& c : classes) { bytes += c.uri; offs.push_back(bytes.size()); masks.push_back(c.mask); }
+    bytes += "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>";
+    offs.push_back(bytes.size());
+    std::vector<int64_t> ids(offs.size() - 1);
+    dict_lookup(ctx, bytes.data(), offs.data(), ids.size(), ids.data());
+    type_term = ids.back();
+    if (!classes.empty() && n_terms) {
+      DevBuf<int64_t> dids(pool, classes.size());
+      DevBuf<uint64_t> dmask(pool, classes.size());
+      DX_HIP(hipMemcpyAsync(dids.p, ids.data(), classes.size() * 8, hipMemcpyHostToDevice, s));
+      DX_HIP(hipMemcpyAsync(dmask.p, masks.data(), classes.size() * 8, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_set_class_masks, dim3(blocks(classes.size())), dim3(256), 0, s, dids.p, dmask.p, (uint32_t)classes.size(), Pm.p);
+      DX_HIP(hipStreamSynchronize(s));  // ids/masks vectors go out of scope
+    }
+  }
+  if (n_rec) hipLaunchKernelGGL(k_vertex_masks, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, O.p, kind.p, n_rec, Pm.p, M.p);
+  tm.mark();
+
+  // ---- 6. predicates, sort keys
+  DevBuf<uint32_t> pred_index(pool, (size_t)n_terms + 1);
+  exclusive_scan_u8_u32(pool, is_pred.p, pred_index.p, n_terms, d_total.p, s);
+  uint32_t np = 0;
+  DX_HIP(hipMemcpyAsync(&np, d_total.p, 4, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  st.n_predicates = np;
+  {
+    std::vector<uint8_t> hp(n_terms);
+    if (n_terms) DX_HIP(hipMemcpy(hp.data(), is_pred.p, n_terms, hipMemcpyDeviceToHost));
+    for (uint32_t t = 0; t < n_terms; ++t)
+      if (hp[t]) ps.pred_terms.push_back(t);
+  }
+  const int bits_term = bits_for(n_terms ? n_terms : 1), bits_pred = bits_for(np ? np : 1);
+  if (bits_pred + 2 * bits_term > 64 || 6 + bits_term + 1 + bits_pred > 64)
+    throw DxError(DX_E_RANGE, "dictionary too large for 64-bit packed sort keys on one GPU");
+  ps.bits_term = bits_term;
+  for (uint32_t i = 0; i < np; ++i)
+    if (ps.pred_terms[i] == type_term) ps.type_pidx = i;
+  ps.uniq = DevBuf<uint64_t>(pool, n_rec);
+  ps.n_uniq_slots = n_rec;
+  if (n_rec) hipLaunchKernelGGL(k_pack_keys, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, P.p, O.p, n_rec, pred_index.p, bits_term, ps.uniq.p);
+  S.reset(); P.reset(); O.reset(); kind.reset(); is_pred.reset();
+  radix_sort_u64(pool, ps.uniq.p, nullptr, n_rec, bits_pred + 2 * bits_term, s);
+  tm.mark();
+
+  // ---- 7. placement masks
+  DevBuf<uint64_t> mask(pool, n_rec);
+  DevBuf<uint8_t> node_flag(pool, n_rec);
+  DevBuf<unsigned long long> counters(pool, 2);
+  DX_HIP(hipMemsetAsync(counters.p, 0, 16, s));
+  if (n_rec)
+    hipLaunchKernelGGL(k_place, dim3(blocks(n_rec)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
+                       mask.p, node_flag.p, counters.p);
+  tm.mark();
+
+  // ---- 8. stable split by partition
+  const unsigned sp_tiles = (unsigned)((n_rec + SP_TILE - 1) / SP_TILE) ? (unsigned)((n_rec + SP_TILE - 1) / SP_TILE) : 1;
+  DevBuf<uint32_t> sp_counts(pool, (size_t)nparts * sp_tiles + 1);
+  DX_HIP(hipMemsetAsync(sp_counts.p, 0, sp_counts.bytes(), s));
+  if (n_rec) hipLaunchKernelGGL(k_split_count, dim3(sp_tiles), dim3(SP_THREADS), 0, s, mask.p, n_rec, nparts, sp_counts.p, sp_tiles);
+  exclusive_scan_u32_u32(pool, sp_counts.p, sp_counts.p, (size_t)nparts * sp_tiles + 1, nullptr, s);
+  std::vector<uint32_t> h_part_base(nparts + 1);
+  for (int q = 0; q <= nparts; ++q)
+    DX_HIP(hipMemcpyAsync(&h_part_base[q], sp_counts.p + (size_t)q * sp_tiles, 4, hipMemcpyDeviceToHost, s));
+  unsigned long long h_counters[2] = {0, 0};
+  DX_HIP(hipMemcpyAsync(h_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  st.n_unique = h_counters[0];
+  st.n_edges = h_counters[1];
+  const uint32_t n_rows = h_part_base[nparts];
+  st.n_rows = n_rows;
+  ps.part_base.assign(h_part_base.begin(), h_part_base.end());
+  ps.row_s = DevBuf<int64_t>(pool, n_rows);
+  ps.row_o = DevBuf<int64_t>(pool, n_rows);
+  ps.row_p = DevBuf<uint32_t>(pool, n_rows);
+  if (n_rec)
+    hipLaunchKernelGGL(k_split_scatter, dim3(sp_tiles), dim3(SP_THREADS), 0, s, ps.uniq.p, mask.p, n_rec, nparts, bits_term, sp_counts.p,
+                       sp_tiles, ps.row_s.p, ps.row_o.p, ps.row_p.p);
+  DevBuf<uint32_t> d_part_base(pool, nparts + 1);
+  DX_HIP(hipMemcpyAsync(d_part_base.p, h_part_base.data(), (nparts + 1) * 4, hipMemcpyHostToDevice, s));
+  std::vector<uint32_t> h_tstart;
+  {
+    const size_t nt = (size_t)nparts * (np ? np : 1);
+    DevBuf<uint32_t> tstart(pool, nt);
+    DX_HIP(hipMemsetAsync(tstart.p, 0xFF, nt * 4, s));
+    if (n_rows) hipLaunchKernelGGL(k_table_starts, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_p.p, d_part_base.p, nparts, np, tstart.p);
+    h_tstart.resize(nt);
+    DX_HIP(hipMemcpyAsync(h_tstart.data(), tstart.p, nt * 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+  }
+  tm.mark();
+
+  // ---- 9. node index
+  DevBuf<uint32_t> node_pos(pool, n_rec);
+  exclusive_scan_u8_u32(pool, node_flag.p, node_pos.p, n_rec, d_total.p, s);
+  uint32_t n_node = 0;
+  DX_HIP(hipMemcpyAsync(&n_node, d_total.p, 4, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  ps.n_node = n_node;
+  st.n_node_index = n_node;
+  ps.node_s = DevBuf<int64_t>(pool, n_node);
+  ps.node_o = DevBuf<int64_t>(pool, n_node);
+  if (n_rec) hipLaunchKernelGGL(k_node_index, dim3(blocks(n_rec)), dim3(256), 0, s, ps.uniq.p, node_flag.p, node_pos.p, n_rec, bits_term,
+                                ps.node_s.p, ps.node_o.p, ps.term_flags.p);
+  tm.mark();
+  node_pos.reset(); node_flag.reset(); mask.reset();
+
+  // ---- 10. VP index
+  ps.vpi_bits_term = bits_term;
+  ps.vpi_bits_pred = bits_pred;
+  ps.vpi_base.assign(nparts + 1, 0);
+  if (n_rows) {
+    DevBuf<uint8_t> cnt(pool, n_rows);
+    DevBuf<uint32_t> pos(pool, n_rows);
+    hipLaunchKernelGGL(k_vpi_emit<false>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
+                       ps.type_pidx, ps.term_flags.p, bits_term, bits_pred, cnt.p, nullptr, nullptr);
+    exclusive_scan_u8_u32(pool, cnt.p, pos.p, n_rows, d_total.p, s);
+    uint32_t n_ent = 0;
+    DX_HIP(hipMemcpyAsync(&n_ent, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    DevBuf<uint64_t> ent(pool, n_ent);
+    hipLaunchKernelGGL(k_vpi_emit<true>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
+                       ps.type_pidx, ps.term_flags.p, bits_term, bits_pred, nullptr, pos.p, ent.p);
+    cnt.reset(); pos.reset();
+    radix_sort_u64(pool, ent.p, nullptr, n_ent, 6 + bits_term + 1 + bits_pred, s);
+    DevBuf<uint8_t> fl(pool, n_ent);
+    DevBuf<uint32_t> fp(pool, n_ent);
+    if (n_ent) hipLaunchKernelGGL(k_flag_distinct, dim3(blocks(n_ent)), dim3(256), 0, s, ent.p, n_ent, fl.p);
+    exclusive_scan_u8_u32(pool, fl.p, fp.p, n_ent, d_total.p, s);
+    uint32_t n_vpi = 0;
+    DX_HIP(hipMemcpyAsync(&n_vpi, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    ps.vpi = DevBuf<uint64_t>(pool, n_vpi);
+    if (n_ent) hipLaunchKernelGGL(k_compact_u64, dim3(blocks(n_ent)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_ent, ps.vpi.p);
+    DevBuf<uint32_t> vb(pool, nparts + 1);
+    hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi.p, n_vpi, bits_term + 1 + bits_pred, nparts, vb.p);
+    std::vector<uint32_t> hvb(nparts + 1);
+    DX_HIP(hipMemcpyAsync(hvb.data(), vb.p, (nparts + 1) * 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q <= nparts; ++q) ps.vpi_base[q] = hvb[q];
+    st.n_vp_index = n_vpi;
+  }
+  tm.mark();
+  DX_HIP(hipStreamSynchronize(s));
+  DX_HIP(hipGetLastError());
+
+  // ---- host-side catalogue of tables
+  {
+    std::vector<int64_t> ids(ps.pred_terms.begin(), ps.pred_terms.end());
+    std::vector<uint64_t> offs(np + 1);
+    uint64_t total = 0;
+    if (np) {
+      std::vector<uint64_t> po(np * 2);
+      // predicate strings: fetch offsets one by one (np is small next to the data)
+      for (uint32_t i = 0; i < np; ++i)
+        DX_HIP(hipMemcpy(&po[2 * i], d.pool_off.p + ids[i], 16, hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < np; ++i) {
+        std::string str(po[2 * i + 1] - po[2 * i], '\0');
+        if (!str.empty()) DX_HIP(hipMemcpy(&str[0], d.pool.p + po[2 * i], str.size(), hipMemcpyDeviceToHost));
+        ps.pred_strings.push_back(str);
+        ps.pred_storage.push_back(uri_to_storage(str));
+        total += str.size();
+      }
+    }
+    (void)total; (void)offs;
+    for (int q = 0; q < nparts; ++q) {
+      uint64_t end = h_part_base[q + 1];
+      for (int64_t p = (int64_t)np - 1; p >= 0; --p) {
+        const uint32_t stt = h_tstart[(size_t)q * np + p];
+        if (stt == kNil) continue;
+        VpTable t;
+        t.partition = q; t.pidx = (uint32_t)p; t.pred_term = ps.pred_terms[p];
+        t.begin = stt; t.rows = end - stt;
+        t.in_layout = utf16_units(ps.pred_strings[p]) < 150;  // DAP.scala:434
+        ps.tables.push_back(t);
+        end = stt;
+      }
+    }
+    std::sort(ps.tables.begin(), ps.tables.end(), [](const VpTable& a, const VpTable& b) {
+      return a.partition != b.partition ? a.partition < b.partition : a.pidx < b.pidx;
+    });
+    st.n_tables = (uint32_t)ps.tables.size();
+  }
+  // vertices = terms flagged as vertex
+  {
+    std::vector<uint8_t> hf(n_terms);
+    if (n_terms) DX_HIP(hipMemcpy(hf.data(), ps.term_flags.p, n_terms, hipMemcpyDeviceToHost));
+    uint64_t nv = 0;
+    for (auto f : hf) nv += (f & kFlagVertex) ? 1 : 0;
+    st.n_vertices = nv;
+  }
+
+  // ---- stage times
+  std::vector<float> gaps;
+  for (size_t i = 1; i < tm.ev.size(); ++i) {
+    float ms = 0;
+    DX_HIP(hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]));
+    gaps.push_back(ms);
+  }
+  // event layout: [0]start [1]line_scan [2]tokenise+dictionary+encode [3]pool [4]masks [5]sort [6]place [7]split [8]node [9]vpi
+  st.ms_stage[0] = gaps[0];
+  st.ms_stage[1] = ms_tok;
+  st.ms_stage[2] = gaps[1] - ms_tok;
+  for (int i = 3; i <= 9; ++i) st.ms_stage[i] = gaps[i - 1];
+  float total = 0;
+  DX_HIP(hipEventElapsedTime(&total, tm.ev.front(), tm.ev.back()));
+  st.ms_total = total;
+  (void)ms_dict;
+  ps.valid = true;
+}
+
+}  // namespace dx

@@ -1,0 +1,582 @@
+// Query hot path: execution of a translated basic graph pattern on vertical-partition tables in HBM.
+//
+// The reference hands the SQL text to Spark (QueryProcessor.executeFinalQuery, QueryProcessor.scala:184-195):
+// per sub-select a cached-table scan with string equality filters, then sort-merge joins with a 200-way
+// exchange per join, then count (:173-176). Here every table is a pair of int64 columns, constants are
+// resolved to term ids on the device, and the plan is left-deep:
+//
+//   * the running intermediate is always the hash-join build side (chained table: heads[] + next[],
+//     one atomicExch per row, duplicate keys welcome);
+//   * every base table is streamed exactly once, coalesced, with its constant filters fused into the
+//     probe; matches are appended with one atomic per wave;
+//   * the last step of a count query only counts;
+//   * nothing returns to the host between steps: row counts live in device counters, kernels clamp to
+//     their buffers' capacities, and the host reads all counters once at the end. A step that outgrew
+//     its optimistic capacity is detected there (its counter holds the exact size needed) and the
+//     statement is run again with that capacity.
+#include <algorithm>
+#include <cmath>
+
+#include "dx_device.h"
+#include "dx_sql.h"
+#include "dx_state.h"
+
+namespace dx {
+namespace {
+
+constexpr int MAXC = 10;
+constexpr int MAXSTEPS = 30;
+constexpr int kConstBytes = 3072;
+constexpr int kMaxConsts = 32;
+
+struct RelDev {
+  int64_t* col[MAXC];
+  int ncols;
+  uint32_t cap;
+  const unsigned long long* count;
+};
+__device__ __forceinline__ uint32_t rel_rows(const RelDev& r) {
+  const unsigned long long c = *r.count;
+  return c < r.cap ? (uint32_t)c : r.cap;
+}
+
+struct ArmDev {
+  const int64_t* s;
+  const int64_t* o;
+  uint32_t rows;
+  int fs, fo;      // index into consts of the s / o filter, -1 = none
+  int nsrc;
+  int src[3];      // 0 = s, 1 = o, 2 = constant
+  int src_ci[3];
+};
+
+struct ConstArgs {
+  char bytes[kConstBytes];
+  uint32_t off[kMaxConsts + 1];
+  long long preset[kMaxConsts];  // LLONG_MIN = look the string up, anything else = the id to use
+  int n;
+};
+
+__device__ __forceinline__ uint64_t hash_key(int64_t a) { return mix64((uint64_t)a * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull); }
+__device__ __forceinline__ uint64_t hash_key2(int64_t a, int64_t b) { return mix64(hash_key(a) ^ ((uint64_t)b * 0xC2B2AE3D27D4EB4Full)); }
+
+// Constants -> term ids, on the device, so the host never waits for them.
+__global__ void __launch_bounds__(64)
+k_resolve_consts(ConstArgs ca, uint64_t seed, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, uint64_t mask,
+                 const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i >= ca.n) return;
+  if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) { out[i] = ca.preset[i]; return; }
+  const uint32_t b = ca.off[i], e = ca.off[i + 1];
+  TermHash th(seed);
+  for (uint32_t j = b; j < e; ++j) th.add((uint8_t)ca.bytes[j]);
+  const uint64_t h = th.finish(e - b);
+  uint64_t slot = h & mask;
+  int64_t res = -1;
+  for (;;) {
+    const uint64_t cur = keys[slot];
+    if (cur == 0) break;
+    if (cur == h) {
+      const uint32_t id = ids[slot];
+      const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
+      bool same = pl == e - b;
+      for (uint64_t j = 0; same && j < pl; ++j) same = pool[pb + j] == (uint8_t)ca.bytes[b + j];
+      if (same) res = id;
+      break;
+    }
+    slot = (slot + 1) & mask;
+  }
+  out[i] = res;
+}
+
+__device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, uint32_t i, int64_t v[3]) {
+  // columnar: the filtered column is read first, the other one only for rows that pass
+  int64_t s = 0, o = 0;
+  if (a.fo >= 0) { o = a.o[i]; if (o != consts[a.fo]) return false; }
+  if (a.fs >= 0) { s = a.s[i]; if (s != consts[a.fs]) return false; }
+  bool need_s = false, need_o = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < a.nsrc) { need_s |= a.src[k] == 0; need_o |= a.src[k] == 1; }
+  if (need_s && a.fs < 0) s = a.s[i];
+  if (need_o && a.fo < 0) o = a.o[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < a.nsrc) v[k] = a.src[k] == 0 ? s : a.src[k] == 1 ? o : consts[a.src_ci[k]];
+  return true;
+}
+
+// Filtered scan that only counts (single-relation count queries).
+__global__ void __launch_bounds__(256)
+k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* __restrict__ total) {
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.rows; i += gridDim.x * blockDim.x) {
+    int64_t v[3];
+    c += arm_row(a, consts, i, v) ? 1u : 0u;
+  }
+  c = wave_reduce_u32(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
+}
+
+// Filtered scan that appends the projected tuple to `out` (first relation of a plan).
+__global__ void __launch_bounds__(256)
+k_scan_emit(ArmDev a, const int64_t* __restrict__ consts, RelDev out, unsigned long long* __restrict__ out_count) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (a.rows + stride - 1) / stride;
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t v[3];
+    const bool hit = i < a.rows && arm_row(a, consts, i, v);
+    const uint64_t b = __ballot(hit);
+    if (!b) continue;
+    unsigned long long base = 0;
+    if (lane == __ffsll((unsigned long long)b) - 1) base = atomicAdd(out_count, (unsigned long long)__popcll(b));
+    base = __shfl(base, __ffsll((unsigned long long)b) - 1, 64);
+    if (hit) {
+      const unsigned long long pos = base + __popcll(b & lt);
+      if (pos < out.cap) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < a.nsrc) out.col[k][pos] = v[k];
+      }
+    }
+  }
+}
+
+struct BuildArgs {
+  RelDev I;
+  int nkey;
+  int key_col[2];
+  uint32_t* heads;
+  uint32_t* next;
+  uint32_t hmask;
+};
+__global__ void __launch_bounds__(256) k_build(BuildArgs b) {
+  const uint32_t n = rel_rows(b.I);
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const int64_t k0 = b.I.col[b.key_col[0]][r];
+    const uint64_t h = b.nkey == 2 ? hash_key2(k0, b.I.col[b.key_col[1]][r]) : hash_key(k0);
+    b.next[r] = atomicExch(&b.heads[(uint32_t)h & b.hmask], r);
+  }
+}
+
+struct ProbeArgs {
+  ArmDev arm;
+  const int64_t* consts;
+  RelDev I;
+  const uint32_t* heads;
+  const uint32_t* next;
+  uint32_t hmask;
+  int nkey;
+  int key_src[2];   // position in the arm's tuple
+  int key_col[2];   // column of the intermediate
+  int nnew;
+  int new_src[3];   // positions of the arm's tuple that become new columns
+  RelDev out;       // columns: I's, then the new ones
+  unsigned long long* out_count;
+  int count_only;
+};
+
+// Streams one base-table arm and probes the intermediate's hash table. nkey == 0 is the cross product.
+__global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (p.arm.rows + stride - 1) / stride;
+  const uint32_t nI = rel_rows(p.I);
+  unsigned long long local = 0;
+  for (uint32_t rd = 0; rd < rounds; ++rd) {
+    const uint32_t i = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t v[3];
+    const bool hit = i < p.arm.rows && arm_row(p.arm, p.consts, i, v);
+    uint32_t r = kNil;
+    int64_t k0 = 0, k1 = 0;
+    if (hit) {
+      if (p.nkey == 0) {
+        r = nI ? 0u : kNil;
+      } else {
+        k0 = v[p.key_src[0]];
+        if (p.nkey == 2) k1 = v[p.key_src[1]];
+        const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
+        r = p.heads[(uint32_t)h & p.hmask];
+      }
+    }
+    while (__any(r != kNil)) {
+      bool match = false;
+      if (r != kNil) {
+        match = p.nkey == 0 || (p.I.col[p.key_col[0]][r] == k0 && (p.nkey < 2 || p.I.col[p.key_col[1]][r] == k1));
+      }
+      if (p.count_only) {
+        local += match ? 1 : 0;
+      } else {
+        const uint64_t b = __ballot(match);
+        if (b) {
+          const int leader = __ffsll((unsigned long long)b) - 1;
+          unsigned long long base = 0;
+          if (lane == leader) base = atomicAdd(p.out_count, (unsigned long long)__popcll(b));
+          base = __shfl(base, leader, 64);
+          if (match) {
+            const unsigned long long pos = base + __popcll(b & lt);
+            if (pos < p.out.cap) {
+              for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
+              for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = v[p.new_src[c]];
+            }
+          }
+        }
+      }
+      if (r != kNil) {
+        if (p.nkey == 0) r = (r + 1 < nI) ? r + 1 : kNil;
+        else r = p.next[r];
+      }
+    }
+  }
+  if (p.count_only) {
+    local = wave_reduce_u64(local);
+    if (lane == 0 && local) atomicAdd(p.out_count, local);
+  }
+}
+
+// ---- planning ----------------------------------------------------------------------------------------
+struct PlanRel {
+  int ncols = 0;
+  int cls[3] = {-1, -1, -1};     // variable class of each projected column
+  struct Arm {
+    const CatalogTable* t;
+    int fs = -1, fo = -1;
+    int src[3] = {0, 0, 0}, src_ci[3] = {-1, -1, -1};
+  };
+  std::vector<Arm> arms;
+  uint64_t rows_upper = 0;
+  double est = 0;
+};
+
+struct Plan {
+  std::vector<PlanRel> rels;     // in execution order
+  std::vector<std::string> const_str;
+  std::vector<long long> const_preset;
+  std::vector<int> select_cls;
+  std::vector<std::string> select_names;
+  std::vector<std::string> virtual_terms;
+  int n_classes = 0;
+};
+
+int find_root(std::vector<int>& uf, int x) { while (uf[x] != x) x = uf[x] = uf[uf[x]]; return x; }
+
+Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
+  Plan plan;
+  const long long kLookup = (-0x7FFFFFFFFFFFFFFFll - 1);
+  auto add_const = [&](const std::string& s, bool is_virtual) -> int {
+    for (size_t i = 0; i < plan.const_str.size(); ++i)
+      if (plan.const_str[i] == s && (plan.const_preset[i] != kLookup) == is_virtual) return (int)i;
+    long long preset = kLookup;
+    if (is_virtual) {
+      plan.virtual_terms.push_back(s);
+      preset = -(long long)(2 + plan.virtual_terms.size() - 1);
+    }
+    plan.const_str.push_back(s);
+    plan.const_preset.push_back(preset);
+    return (int)plan.const_str.size() - 1;
+  };
+  // variable classes: union-find over (sub, column)
+  std::vector<std::pair<int, int>> slots;
+  auto slot_of = [&](const std::string& alias, const std::string& col) -> int {
+    for (size_t si = 0; si < q.subs.size(); ++si)
+      if (q.subs[si].alias == alias)
+        for (size_t c = 0; c < q.subs[si].arms[0].proj.size(); ++c)
+          if (q.subs[si].arms[0].proj[c].name == col) {
+            for (size_t k = 0; k < slots.size(); ++k)
+              if (slots[k].first == (int)si && slots[k].second == (int)c) return (int)k;
+          }
+    throw DxError(DX_E_MALFORMED, "SQL: unknown column " + alias + "." + col);
+  };
+  for (size_t si = 0; si < q.subs.size(); ++si) {
+    const auto& pr = q.subs[si].arms[0].proj;
+    if (pr.empty() || pr.size() > 3) throw DxError(DX_E_UNSUPPORTED, "SQL: sub-select with " + std::to_string(pr.size()) + " columns");
+    for (size_t c = 0; c < pr.size(); ++c) {
+      for (size_t c2 = 0; c2 < c; ++c2)
+        if (pr[c2].name == pr[c].name) throw DxError(DX_E_UNSUPPORTED, "SQL: one variable bound to two columns of a sub-select");
+      slots.emplace_back((int)si, (int)c);
+    }
+    for (size_t sj = 0; sj < si; ++sj)
+      if (q.subs[sj].alias == q.subs[si].alias) throw DxError(DX_E_MALFORMED, "SQL: duplicate alias " + q.subs[si].alias);
+  }
+  std::vector<int> uf(slots.size());
+  for (size_t i = 0; i < uf.size(); ++i) uf[i] = (int)i;
+  for (const auto& c : q.conds) {
+    const int a = find_root(uf, slot_of(c.a_alias, c.a_col)), b = find_root(uf, slot_of(c.b_alias, c.b_col));
+    if (a != b) uf[a] = b;
+  }
+  std::vector<int> cls_of(slots.size(), -1);
+  for (size_t i = 0; i < slots.size(); ++i) {
+    const int r = find_root(uf, (int)i);
+    if (cls_of[r] < 0) cls_of[r] = plan.n_classes++;
+    cls_of[i] = cls_of[r];
+  }
+  if (plan.n_classes > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: more than " + std::to_string(MAXC) + " variables");
+  for (const auto& it : q.select) {
+    plan.select_cls.push_back(cls_of[slot_of(it.alias, it.col)]);
+    plan.select_names.push_back(it.name);
+  }
+  // relations
+  std::vector<PlanRel> rels;
+  size_t slot_i = 0;
+  for (size_t si = 0; si < q.subs.size(); ++si) {
+    const SqlSub& sub = q.subs[si];
+    PlanRel r;
+    r.ncols = (int)sub.arms[0].proj.size();
+    for (int c = 0; c < r.ncols; ++c) r.cls[c] = cls_of[slot_i + c];
+    slot_i += r.ncols;
+    for (int c = 0; c < r.ncols; ++c)
+      for (int c2 = 0; c2 < c; ++c2)
+        if (r.cls[c] == r.cls[c2]) throw DxError(DX_E_UNSUPPORTED, "SQL: join condition between two columns of one sub-select");
+    double sel = 1.0;
+    std::vector<std::string> seen;
+    for (const SqlArm& arm : sub.arms) {
+      std::string sig = arm.table + "\x02" + (arm.has_s ? arm.s_const : "\x03") + "\x02" + (arm.has_o ? arm.o_const : "\x03");
+      for (const auto& p : arm.proj) sig += "\x02" + std::to_string(p.src) + p.constant;
+      if (std::find(seen.begin(), seen.end(), sig) != seen.end()) continue;  // UNION is a set union: identical arms collapse
+      seen.push_back(sig);
+      auto it = ctx->catalog.find(arm.table);
+      if (it == ctx->catalog.end()) throw DxError(DX_E_NOENT, "SQL: table or view not found: " + arm.table);
+      PlanRel::Arm a;
+      a.t = &it->second;
+      if (arm.has_s) a.fs = add_const(arm.s_const, false);
+      if (arm.has_o) a.fo = add_const(arm.o_const, false);
+      for (int c = 0; c < r.ncols; ++c) {
+        a.src[c] = arm.proj[c].src;
+        if (a.src[c] == 2) a.src_ci[c] = add_const(arm.proj[c].constant, true);
+      }
+      r.arms.push_back(a);
+      r.rows_upper += it->second.rows;
+      const bool type_table = arm.table.size() > 6 && arm.table.rfind("_type_") == arm.table.size() - 6;
+      sel = arm.has_s ? 1e-4 : arm.has_o ? (type_table ? 0.2 : 1e-4) : 1.0;
+    }
+    r.est = (double)r.rows_upper * sel;
+    rels.push_back(std::move(r));
+  }
+  if ((int)plan.const_str.size() > kMaxConsts) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 32 constants");
+  // greedy left-deep order: cheapest first, then always the cheapest relation sharing a bound variable
+  std::vector<bool> used(rels.size(), false), bound(plan.n_classes, false);
+  for (size_t k = 0; k < rels.size(); ++k) {
+    int best = -1;
+    bool best_conn = false;
+    for (size_t i = 0; i < rels.size(); ++i) {
+      if (used[i]) continue;
+      bool conn = false;
+      for (int c = 0; c < rels[i].ncols; ++c) conn |= bound[rels[i].cls[c]];
+      if (best < 0 || (conn && !best_conn) || (conn == best_conn && rels[i].est < rels[best].est)) { best = (int)i; best_conn = conn; }
+    }
+    used[best] = true;
+    for (int c = 0; c < rels[best].ncols; ++c) bound[rels[best].cls[c]] = true;
+    plan.rels.push_back(rels[best]);
+  }
+  if ((int)plan.rels.size() > MAXSTEPS) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 30 sub-selects");
+  return plan;
+}
+
+ArmDev arm_dev(const PlanRel& r, const PlanRel::Arm& a) {
+  ArmDev d{};
+  d.s = a.t->s; d.o = a.t->o; d.rows = (uint32_t)a.t->rows;
+  d.fs = a.fs; d.fo = a.fo; d.nsrc = r.ncols;
+  for (int c = 0; c < 3; ++c) { d.src[c] = a.src[c]; d.src_ci[c] = a.src_ci[c]; }
+  return d;
+}
+
+unsigned scan_grid(uint64_t rows) {
+  uint64_t g = (rows + 255) / 256;
+  if (g < 1) g = 1;
+  return (unsigned)(g > 2048 ? 2048 : g);
+}
+
+}  // namespace
+
+// Pinned host block the final counters land in.
+struct QueryHostBlock {
+  unsigned long long counters[MAXSTEPS + 2];
+};
+
+dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
+  const SqlQuery q = parse_sql(sql);
+  Plan plan = make_plan(ctx, q);
+  if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
+  for (auto& r : plan.rels)
+    for (auto& a : r.arms)
+      if (a.t->rows >= (1ull << 32)) throw DxError(DX_E_RANGE, "table with 2^32 rows or more");
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  const int nsteps = (int)plan.rels.size();
+
+  ConstArgs ca;
+  ca.n = (int)plan.const_str.size();
+  uint32_t off = 0;
+  for (int i = 0; i < ca.n; ++i) {
+    ca.off[i] = off;
+    ca.preset[i] = plan.const_preset[i];
+    if (off + plan.const_str[i].size() > (size_t)kConstBytes) throw DxError(DX_E_UNSUPPORTED, "SQL: constants exceed 3 KiB in total");
+    memcpy(ca.bytes + off, plan.const_str[i].data(), plan.const_str[i].size());
+    off += (uint32_t)plan.const_str[i].size();
+  }
+  ca.off[ca.n] = off;
+
+  static thread_local QueryHostBlock* hb = nullptr;
+  if (!hb) DX_HIP(hipHostMalloc((void**)&hb, sizeof(QueryHostBlock), hipHostMallocDefault));
+
+  std::vector<uint64_t> caps(nsteps, 0);
+  hipEvent_t ev0, ev1;
+  DX_HIP(hipEventCreate(&ev0));
+  DX_HIP(hipEventCreate(&ev1));
+  auto* res = new dx_result();
+  res->ctx = ctx;
+  res->names = plan.select_names;
+  res->virtual_terms = plan.virtual_terms;
+  try {
+    for (int attempt = 0; attempt <= nsteps + 1; ++attempt) {
+      DevBuf<int64_t> consts(pool, kMaxConsts);
+      DevBuf<unsigned long long> counters(pool, MAXSTEPS + 2);
+      std::vector<std::vector<DevBuf<int64_t>>> step_cols(nsteps);
+      std::vector<DevBuf<uint32_t>> tmp32;
+      DX_HIP(hipEventRecord(ev0, s));
+      DX_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * (MAXSTEPS + 2), s));
+      if (ca.n)
+        hipLaunchKernelGGL(k_resolve_consts, dim3(1), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht_keys.p, ctx->dict.ht_ids.p,
+                           ctx->dict.ht_mask, ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
+      RelDev I{};
+      std::vector<int> I_cls;
+      std::vector<uint64_t> step_cap(nsteps, 0);
+      for (int k = 0; k < nsteps; ++k) {
+        const PlanRel& r = plan.rels[k];
+        const bool last = k == nsteps - 1;
+        const bool count_only = last && mode == DX_QUERY_COUNT;
+        unsigned long long* cnt = counters.p + k;
+        if (k == 0) {
+          if (count_only) {
+            for (const auto& a : r.arms)
+              if (a.t->rows) hipLaunchKernelGGL(k_scan_count, dim3(scan_grid(a.t->rows)), dim3(256), 0, s, arm_dev(r, a), consts.p, cnt);
+            break;
+          }
+          const bool alias = r.arms.size() == 1 && r.arms[0].fs < 0 && r.arms[0].fo < 0 && r.arms[0].src[0] != 2 &&
+                             (r.ncols < 2 || r.arms[0].src[1] != 2) && r.ncols <= 2 && mode == DX_QUERY_COUNT;
+          I = RelDev{};
+          I.ncols = r.ncols;
+          I.count = cnt;
+          if (alias) {  // unfiltered single table: use its columns in place
+            const CatalogTable* t = r.arms[0].t;
+            for (int c = 0; c < r.ncols; ++c) I.col[c] = const_cast<int64_t*>(r.arms[0].src[c] == 0 ? t->s : t->o);
+            I.cap = (uint32_t)t->rows;
+            DX_HIP(hipMemcpyAsync(cnt, &t->rows, 8, hipMemcpyHostToDevice, s));
+            step_cap[k] = t->rows;
+          } else {
+            const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : r.rows_upper, 1);
+            for (int c = 0; c < r.ncols; ++c) { step_cols[k].emplace_back(pool, cap); I.col[c] = step_cols[k].back().p; }
+            I.cap = (uint32_t)cap;
+            step_cap[k] = cap;
+            for (const auto& a : r.arms)
+              if (a.t->rows) hipLaunchKernelGGL(k_scan_emit, dim3(scan_grid(a.t->rows)), dim3(256), 0, s, arm_dev(r, a), consts.p, I, cnt);
+          }
+          I_cls.assign(r.cls, r.cls + r.ncols);
+          continue;
+        }
+        // join with the running intermediate
+        ProbeArgs pa{};
+        pa.consts = consts.p;
+        pa.I = I;
+        pa.nkey = 0;
+        pa.nnew = 0;
+        std::vector<int> new_cls;
+        for (int c = 0; c < r.ncols; ++c) {
+          int at = -1;
+          for (size_t j = 0; j < I_cls.size(); ++j)
+            if (I_cls[j] == r.cls[c]) at = (int)j;
+          if (at >= 0) {
+            if (pa.nkey < 2) { pa.key_src[pa.nkey] = c; pa.key_col[pa.nkey] = at; ++pa.nkey; }
+            else throw DxError(DX_E_UNSUPPORTED, "SQL: join on three columns of one sub-select");
+          } else {
+            pa.new_src[pa.nnew++] = c;
+            new_cls.push_back(r.cls[c]);
+          }
+        }
+        if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
+        if (pa.nkey > 0) {
+          uint32_t hsize = 1024;
+          while (hsize < 2ull * I.cap && hsize < (1u << 31)) hsize <<= 1;
+          tmp32.emplace_back(pool, hsize);
+          uint32_t* heads = tmp32.back().p;
+          tmp32.emplace_back(pool, std::max<uint32_t>(I.cap, 1));
+          uint32_t* next = tmp32.back().p;
+          DX_HIP(hipMemsetAsync(heads, 0xFF, (size_t)hsize * 4, s));
+          BuildArgs ba{};
+          ba.I = I; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
+          ba.heads = heads; ba.next = next; ba.hmask = hsize - 1;
+          hipLaunchKernelGGL(k_build, dim3(scan_grid(I.cap)), dim3(256), 0, s, ba);
+          pa.heads = heads; pa.next = next; pa.hmask = hsize - 1;
+        }
+        pa.count_only = count_only ? 1 : 0;
+        pa.out_count = cnt;
+        RelDev out{};
+        out.ncols = (int)I_cls.size() + pa.nnew;
+        out.count = cnt;
+        if (!count_only) {
+          const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : std::max<uint64_t>(I.cap, r.rows_upper), 1);
+          if (cap >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
+          for (int c = 0; c < out.ncols; ++c) { step_cols[k].emplace_back(pool, cap); out.col[c] = step_cols[k].back().p; }
+          out.cap = (uint32_t)cap;
+          step_cap[k] = cap;
+        }
+        pa.out = out;
+        for (const auto& a : r.arms) {
+          if (!a.t->rows) continue;
+          pa.arm = arm_dev(r, a);
+          hipLaunchKernelGGL(k_probe, dim3(scan_grid(a.t->rows)), dim3(256), 0, s, pa);
+        }
+        I = out;
+        for (int c : new_cls) I_cls.push_back(c);
+      }
+      DX_HIP(hipMemcpyAsync(hb->counters, counters.p, sizeof(unsigned long long) * (MAXSTEPS + 2), hipMemcpyDeviceToHost, s));
+      DX_HIP(hipEventRecord(ev1, s));
+      DX_HIP(hipStreamSynchronize(s));
+      DX_HIP(hipGetLastError());
+      bool overflow = false;
+      const bool final_counts_only = mode == DX_QUERY_COUNT;
+      for (int k = 0; k < nsteps; ++k) {
+        if (k == nsteps - 1 && final_counts_only) break;
+        if (hb->counters[k] > step_cap[k]) {
+          if (hb->counters[k] >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
+          caps[k] = hb->counters[k];
+          overflow = true;
+          break;  // later counters were computed from a truncated input
+        }
+      }
+      if (overflow) continue;
+      float ms = 0;
+      DX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+      res->device_ms = ms;
+      res->count = hb->counters[nsteps - 1];
+      if (mode == DX_QUERY_BINDINGS) {
+        res->has_bindings = true;
+        for (size_t c = 0; c < plan.select_cls.size(); ++c) {
+          int at = -1;
+          for (size_t j = 0; j < I_cls.size(); ++j)
+            if (I_cls[j] == plan.select_cls[c]) at = (int)j;
+          if (at < 0) throw DxError(DX_E_MALFORMED, "SQL: selected column is not produced by any sub-select");
+          DevBuf<int64_t> col(pool, res->count);
+          if (res->count) DX_HIP(hipMemcpyAsync(col.p, I.col[at], res->count * 8, hipMemcpyDeviceToDevice, s));
+          res->cols.push_back(std::move(col));
+        }
+        DX_HIP(hipStreamSynchronize(s));
+      }
+      (void)hipEventDestroy(ev0);
+      (void)hipEventDestroy(ev1);
+      return res;
+    }
+    throw DxError(DX_E_RANGE, "query did not converge on buffer sizes");
+  } catch (...) {
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    delete res;
+    throw;
+  }
+}
+
+}  // namespace dx

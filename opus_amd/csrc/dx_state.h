@@ -1,0 +1,111 @@
+// Context state: dictionary, partitioner results, table catalogue.
+#pragma once
+#include "dx_internal.h"
+
+namespace dx {
+
+constexpr uint32_t kNil = 0xFFFFFFFFu;
+constexpr int kRepLenBits = 24;  // a term is at most 16 MiB; its first byte sits below 1 TiB
+
+// Term dictionary resident in HBM. id -> bytes through pool/pool_off; bytes -> id through an
+// open-addressing table keyed by the 64-bit term hash (slot -> id), confirmed by byte compare.
+struct Dictionary {
+  uint64_t n_terms = 0;
+  uint64_t seed = 0;
+  DevBuf<uint8_t> pool;        // concatenated term bytes, id order
+  DevBuf<uint64_t> pool_off;   // n_terms + 1
+  DevBuf<uint64_t> ht_keys;    // hash or 0
+  DevBuf<uint32_t> ht_ids;     // id of the slot's term
+  uint64_t ht_mask = 0;
+  bool valid() const { return pool_off.p != nullptr; }
+};
+
+struct ClassIndexEntry {
+  std::string uri;
+  uint64_t mask;
+};
+
+struct VpTable {
+  int32_t partition;
+  uint32_t pidx;          // dense predicate index
+  int64_t pred_term;
+  uint64_t begin, rows;   // slice of the partition-major row arrays
+  bool in_layout;
+};
+
+struct PartitionState {
+  bool valid = false;
+  int n_partitions = 0;
+  dx_part_stats stats{};
+  // rows of all first-level partitions, partition-major; inside a partition sorted by (predicate, s, o)
+  DevBuf<int64_t> row_s, row_o;
+  DevBuf<uint32_t> row_p;             // dense predicate index
+  std::vector<uint64_t> part_base;    // n_partitions + 1
+  std::vector<int64_t> pred_terms;    // pidx -> term id
+  std::vector<std::string> pred_strings, pred_storage;  // pidx -> IRI text, sanitised directory name
+  std::vector<VpTable> tables;        // non-empty ones, ordered by (partition, pidx)
+  // node index
+  DevBuf<int64_t> node_s, node_o;
+  uint64_t n_node = 0;
+  // VP index: sorted unique keys (partition, uri, role, pidx) packed into 64 bits
+  DevBuf<uint64_t> vpi;
+  std::vector<uint64_t> vpi_base;     // n_partitions + 1
+  int vpi_bits_term = 0, vpi_bits_pred = 0;
+  // sorted distinct input triples packed as (pidx, s, o) plus what is needed to unpack them
+  DevBuf<uint64_t> uniq;
+  uint64_t n_uniq_slots = 0;          // length of uniq (duplicates are still in, flagged by equality with the predecessor)
+  int bits_term = 0;
+  uint32_t type_pidx = kNil;
+  DevBuf<uint8_t> term_flags;         // per term: bit0 = literal (starts with '"'), bit1 = vertex, bit2 = has edge
+};
+
+struct CatalogTable {
+  std::string key;      // "00001-_3=<pred>"
+  std::string view;     // "table00001__3_E_<pred>"
+  uint64_t rows = 0;
+  // a view is the concatenation of one or more row slices (several predicates can sanitise to one name)
+  struct Slice { const int64_t* s; const int64_t* o; uint64_t rows; };
+  std::vector<Slice> slices;
+  // owned storage when loaded from disk or when slices had to be concatenated
+  DevBuf<int64_t> own_s, own_o;
+  const int64_t* s = nullptr;
+  const int64_t* o = nullptr;
+};
+
+}  // namespace dx
+
+struct dx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  dx::DevPool pool;
+  dx::Dictionary dict;
+  dx::PartitionState part;
+  std::map<std::string, dx::CatalogTable> catalog;   // by view name
+  // dataset opened from disk
+  std::string ds_base, ds_name;
+  int ds_partitions = 0;
+  // query workspace
+  dx::DevBuf<uint8_t> qws;
+};
+
+struct dx_result {
+  dx_ctx* ctx = nullptr;
+  uint64_t count = 0;
+  double device_ms = 0;
+  bool has_bindings = false;
+  std::vector<std::string> names;
+  std::vector<dx::DevBuf<int64_t>> cols;   // one per selected column (bindings mode)
+  std::vector<std::string> virtual_terms;  // projected constants: id -(2 + index)
+};
+
+namespace dx {
+// dx_hp1.hip
+void run_partition(dx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
+                   int n_partitions);
+void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids_host);
+void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
+// dx_hp2.hip
+dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
+extern const char* const kStageNames[12];
+}  // namespace dx

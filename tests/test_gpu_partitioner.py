@@ -1,0 +1,127 @@
+"""Parity of the HIP partitioner with the CPU restatement (bit-exact, string level)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from opus_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _run(engine, text, ci, n):
+    from oracle import dap_oracle
+    from parity_util import assert_same_as_oracle, engine_artifacts
+    st = engine.partition_text(text.encode("utf-8", "surrogatepass") if isinstance(text, str) else text, ci, n)
+    ref = dap_oracle.run_dap(text if isinstance(text, str) else bytes(text).decode(), ci, n)
+    got = engine_artifacts(engine)
+    assert st.n_triples == ref["n_triples"]
+    assert st.n_vertices == len(ref["vertices"])
+    assert st.n_edges == len(ref["edges"])
+    assert st.n_rows == sum(len(p) for p in ref["parts"])
+    assert_same_as_oracle(got, ref)
+    return st, got, ref
+
+
+def test_golden_known_answer(engine):
+    g = json.load(open(os.path.join(HERE, "golden", "appendix_c.json")))
+    st, got, ref = _run(engine, g["instances"], g["class_index"], g["n_partitions"])
+    assert [set(p) for p in got["parts"]] == [{tuple(t) for t in p} for p in g["parts"]]
+    assert set(got["node_index"]) == {tuple(x) for x in g["node_index"]}
+    assert {k[0] + "/" + k[1]: sorted(v) for k, v in got["vp"].items()} == {k: sorted(tuple(x) for x in v) for k, v in g["vp"].items()}
+    assert got["vertices"] == [v[1] for v in g["vertices"]]
+
+
+def test_lubm1(engine, lubm1):
+    from parity_util import assert_same_as_oracle, engine_artifacts
+    st = engine.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+    assert st.n_triples == lubm1["n_triples"]
+    assert_same_as_oracle(engine_artifacts(engine), lubm1["oracle"])
+
+
+EDGE_CASES = {
+    "duplicates_and_comments": (
+        "# a comment line\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> <p> <b> .\n<a> <p> <b> .\n"
+        "<a> <p> <b> .\n#another\n<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n<a> <l> \"x\" .\n<a> <l> \"x\" .\n",
+        "<A>\t0\n<B>\t1,2\n", 3),
+    "crlf_tabs_no_final_newline": (
+        "<a>\t<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>   <A> .\r\n<a>  <p>\t<b> .\r\n<b> <q> \"lit with  spaces\"@en .\r\n"
+        "<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .",
+        "<A>\t0,1\n", 2),
+    "class_missing_from_index_and_untyped": (
+        "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <Z> .\n<a> <p> <b> .\n<b> <p> <c> .\n<c> <n> \"v\" .\n"
+        "<c> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<d> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n"
+        "<d> <n> \"isolated\" .\n",
+        "<A>\t1\n", 2),
+    "multi_typed_and_literal_datatypes": (
+        "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n"
+        "<a> <p> <b> .\n<a> <n> \"1\"^^<http://www.w3.org/2001/XMLSchema#integer> .\n<b> <n> \"été \U0001F600\" .\n"
+        "<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n<ü> <p> <a> .\n<￮> <p> <a> .\n<\U00010400> <p> <a> .\n",
+        "<A>\t0\n<B>\t2,3\n", 4),
+    "long_predicate_left_out_of_vp": (
+        "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> <" + "p" * 148 + "> <b> .\n<a> <" + "q" * 147 + "> <b> .\n",
+        "<A>\t0\n", 1),
+    "predicates_sharing_a_directory": (
+        "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> <http://x/P-1> <b> .\n<a> <http://x/p_1> <b> .\n"
+        "<a> <http://x/p.1> <c> .\n",
+        "<A>\t0\n", 1),
+    "empty_object_and_leading_space": (
+        "<a> <p> \n <s> <o> .\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n", "<A>\t0\n", 1),
+    "empty_input": ("", "<A>\t0\n", 2),
+    "only_comments": ("# nothing\n# here\n", "<A>\t0\n", 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_CASES))
+def test_edge_cases(engine, name):
+    text, ci, n = EDGE_CASES[name]
+    _run(engine, text, ci, n)
+
+
+@pytest.mark.parametrize("text", ["<a> <p>\n", "<a>\n", "<a> <p> <b> .\n\n<a> <p> <c> .\n", "<a>   \n"])
+def test_malformed_lines_are_errors(engine, text):
+    """The reference throws on lines with fewer than three fields (Preprocessor.scala:121-122)."""
+    from opus_amd.engine import DxError
+    from oracle import dap_oracle
+    with pytest.raises((ValueError, IndexError)):
+        dap_oracle.run_dap(text, "<A>\t0\n", 1)
+    with pytest.raises(DxError) as ei:
+        engine.partition_text(text.encode(), "<A>\t0\n", 1)
+    assert ei.value.code == -74
+
+
+def test_class_index_partition_out_of_range(engine):
+    from opus_amd.engine import DxError
+    with pytest.raises(DxError) as ei:
+        engine.partition_text(b"<a> <p> <b> .\n", "<A>\t5\n", 2)
+    assert ei.value.code == -34
+
+
+def test_random_small_graphs(engine):
+    """Seeded random multi-typed graphs with heavy duplication and many tiny predicates."""
+    rng = np.random.default_rng(7)
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    for trial in range(4):
+        nv, ncls, npred, nparts = 60, 6, 9, int(rng.integers(1, 7))
+        lines = []
+        for _ in range(500):
+            k = rng.integers(0, 3)
+            s = "<v%d>" % rng.integers(0, nv)
+            if k == 0:
+                lines.append("%s %s <C%d> ." % (s, T, rng.integers(0, ncls)))
+            elif k == 1:
+                lines.append('%s <l%d> "val%d" .' % (s, rng.integers(0, 3), rng.integers(0, 20)))
+            else:
+                lines.append("%s <e%d> <v%d> ." % (s, rng.integers(0, npred), rng.integers(0, nv)))
+        ci = "".join("<C%d>\t%s\n" % (c, ",".join(str(x) for x in sorted(set(rng.integers(0, nparts, size=rng.integers(1, 3)).tolist()))))
+                     for c in range(ncls - 1))  # the last class is not indexed
+        _run(engine, "\n".join(lines) + "\n", ci, nparts)

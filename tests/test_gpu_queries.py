@@ -1,0 +1,139 @@
+"""Parity of the HIP query path with SQLite executing the same translated SQL text."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def loaded(lubm1):
+    """Engine with LUBM-1 partitioned, plus translated queries produced from the engine's own
+    node index / statistics by the host-side translator."""
+    from opus_amd import lubm
+    from opus_amd.engine import Engine
+    from opus_amd.host import translator as T
+    from parity_util import engine_artifacts
+    e = Engine(0)
+    e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+    art = engine_artifacts(e)
+    ni = {}
+    for u, c in art["node_index"]:
+        ni.setdefault(u, []).append(c)
+    ci = T.load_class_index(lubm1["class_index"])
+    translated = {}
+    for name, text in lubm.queries(0).items():
+        translated[name] = T.translate_query(name, text, lambda u: ni.get(u, []), ci, art["partition_stat"])
+        assert translated[name] is not None, name
+    yield e, translated
+    e.close()
+
+
+def _run_file(e, text, mode):
+    from oracle.query_oracle import parse_translated_file
+    qm, partitions, tp = parse_translated_file(text)
+    e.unload_all()
+    loaded = sum(e.load_table(p) for p in partitions)
+    assert len(qm) == 1
+    return e.query(next(iter(qm.values())), mode), loaded
+
+
+@pytest.mark.parametrize("name", ["Q%d.txt" % i for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14)])
+def test_lubm_query_counts_and_bindings(loaded, lubm1, name):
+    from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
+    from oracle.query_oracle import run_query
+    e, translated = loaded
+    ref = run_query(lubm1["oracle"]["vp"], translated[name])
+    res, load_rows = _run_file(e, translated[name], DX_QUERY_COUNT)
+    assert res.count == ref["count"], name
+    assert load_rows == ref["load_data"]
+    res_b, _ = _run_file(e, translated[name], DX_QUERY_BINDINGS)
+    assert res_b.count == ref["count"]
+    rows, cols = res_b.rows()
+    assert cols == ref["columns"]
+    assert rows == ref["rows"], name  # sorted decoded bindings, bit-exact
+
+
+def test_reference_translated_q2_example_parses_and_runs(loaded):
+    """The one translated file the reference carries (QueryOptimizer.scala:282) names partitions
+    00001/00002/00004 of an N >= 5 run; against this 4-partition data its tables do not exist."""
+    from opus_amd.engine import DxError
+    from oracle.query_oracle import parse_translated_file
+    e, _ = loaded
+    qm, partitions, tp = parse_translated_file(open(os.path.join(HERE, "golden", "translated_Q2_reference_example.txt")).read())
+    assert tp == 6 and len(partitions) == 6
+    e.unload_all()
+    with pytest.raises(DxError) as ei:  # SQL parses; the first missing view is reported like Spark's "Table or view not found"
+        e.query(qm["X"])
+    assert ei.value.code == -2
+
+
+def test_optimizer_style_rewrite_gives_same_count(loaded, lubm1):
+    """QueryOptimizer reorders FROM and replaces the join chain by another spanning set of equalities."""
+    from oracle.query_oracle import parse_translated_file, run_query
+    e, translated = loaded
+    text = translated["Q9.txt"]
+    qm, partitions, _ = parse_translated_file(text)
+    sql = qm["X"]
+    import re
+    head, where = sql.rsplit(" WHERE ", 1)
+    sel, frm = head.split(" FROM ", 1)
+    subs = re.split(r", (?=\()", frm)
+    assert len(subs) == 6
+    sql2 = sel + " FROM " + ", ".join(reversed(subs)) + " WHERE " + " AND ".join(reversed(where.strip().split(" AND ")))
+    ref = run_query(lubm1["oracle"]["vp"], text)
+    e.unload_all()
+    for p in partitions:
+        e.load_table(p)
+    assert e.query(sql2).count == ref["count"]
+
+
+def test_union_and_constant_projection(loaded, lubm1):
+    """The variable-predicate templates (QueryTranslator.scala:476-533): UNION arms with a constant column."""
+    from opus_amd.engine import DX_QUERY_BINDINGS
+    from oracle.query_oracle import SqliteProcessor, clean_table_name
+    e, translated = loaded
+    O = "http://www.lehigh.edu/~zhp2/2004/0401/univ-bench.owl#"
+    parts = ["00002-_3=" + s for s in ("_http___www_lehigh_edu__zhp2_2004_0401_univ_bench_owl_memberof_",
+                                       "_http___www_lehigh_edu__zhp2_2004_0401_univ_bench_owl_takescourse_",
+                                       "_http___www_w3_org_1999_02_22_rdf_syntax_ns_type_")]
+    e.unload_all()
+    for p in parts:
+        e.load_table(p)
+    arms = "UNION".join("(SELECT s AS X, '<%s>' AS P FROM %s WHERE o == '<http://www.Department0.University0.edu>')" % (p, clean_table_name(p))
+                        for p in parts[:2])
+    sql = ("SELECT tab0.X AS X,tab0.P AS P FROM ( %s ) AS tab0, (SELECT s AS X FROM %s WHERE o == '<%sGraduateStudent>') AS tab1 "
+           "WHERE tab0.X=tab1.X " % (arms, clean_table_name(parts[2]), O))
+    proc = SqliteProcessor(lubm1["oracle"]["vp"])
+    proc.preload(parts)
+    cols, rows = proc.execute({"X": sql})
+    res = e.query(sql, DX_QUERY_BINDINGS)
+    got, gcols = res.rows()
+    order = sorted(range(len(cols)), key=lambda i: cols[i])
+    assert gcols == [cols[i] for i in order]
+    assert got == sorted(tuple(r[i] for i in order) for r in rows)
+    assert res.count == len(rows) > 0
+
+
+def test_unknown_constant_and_empty_result(loaded):
+    e, translated = loaded
+    from oracle.query_oracle import parse_translated_file
+    qm, partitions, _ = parse_translated_file(translated["Q1.txt"])
+    e.unload_all()
+    for p in partitions:
+        e.load_table(p)
+    sql = qm["X"].replace("GraduateCourse0>", "NoSuchCourse>")
+    assert e.query(sql).count == 0
+
+
+def test_sql_errors(loaded):
+    from opus_amd.engine import DxError
+    e, _ = loaded
+    for bad, code in (("SELECT FROM", -74), ("SELECT tab0.X AS X FROM (SELECT p AS X FROM t) AS tab0", -95),
+                      ("SELECT tab0.X AS X FROM (SELECT s AS X FROM nosuchtable) AS tab0", -2)):
+        with pytest.raises(DxError) as ei:
+            e.query(bad)
+        assert ei.value.code == code, bad
