@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DAP post-stage partitioning throughput + LUBM Q1-Q14 query latency on MI355X.
+
+One step = one pass of both hot paths over one synthetic LUBM batch per GPU:
+  1. partition the N-Triples text (already resident in HBM) into first-level partitions, vertical
+     partition tables and indexes (dx_partition_device);
+  2. run the 13 LUBM queries of the reference's query folder (there is no Q13) the way
+     QueryProcessor.executeNonTypeQuery does: tables resident, timed count (dx_query).
+
+Prints ONE JSON line (rank 0). `value` is partitioning throughput in triples/s over all ranks;
+the query geo-mean in ms is carried next to it. With --gpus N > 1 (launched by torchrun, one rank
+per GPU) every rank works on its own block of universities with no cross-rank exchange.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def translated_queries(engine, class_index_text, ontology):
+    """Host-side work that stays outside the timed path: the reference's translator turns SPARQL into
+    SQL from the node index, class index and partition statistics (QueryTranslator.scala:25-119)."""
+    from opus_amd import lubm
+    from opus_amd.host import translator as T
+    strs_cache = {}
+    u, t = engine.node_index()
+    consts = set()
+    parsed = {}
+    for name, text in lubm.queries(ontology).items():
+        pq = T.ParsedQuery(text)
+        parsed[name] = text
+        consts.update(pq.mappings.values())
+    ids = engine.lookup(sorted(consts))
+    want = {int(i): c for i, c in zip(ids, sorted(consts)) if i >= 0}
+    sel = np.isin(u, np.fromiter(want.keys(), dtype=np.int64, count=len(want))) if want else np.zeros(len(u), bool)
+    ni = {}
+    type_strs = engine.decode(np.unique(t[sel])) if sel.any() else []
+    tmap = dict(zip(np.unique(t[sel]).tolist(), type_strs))
+    for uu, tt in zip(u[sel].tolist(), t[sel].tolist()):
+        ni.setdefault(want[uu], []).append(tmap[tt])
+    stat = {}
+    for tb in engine.tables():
+        if tb["in_layout"]:
+            k = "%05d" % tb["partition"]
+            stat[k] = stat.get(k, 0) + tb["rows"]
+    ci = T.load_class_index(class_index_text)
+    out = {}
+    for name, text in parsed.items():
+        tr = T.translate_query(name, text, lambda x: ni.get(x, []), ci, stat)
+        if tr is None:
+            raise RuntimeError("query %s cannot be indexed" % name)
+        out[name] = tr
+    del strs_cache
+    return out
+
+
+def parse_translated(text):
+    """QueryProcessor.main (QueryProcessor.scala:68-88)."""
+    partitions, sql = [], None
+    for line in text.split("\n"):
+        if line.startswith("TP") or line.startswith(">>>>>"):
+            continue
+        if line.startswith("partitions"):
+            partitions = line.split(" ")[1].split(",")
+        elif line:
+            sql = " ".join(line.split(" ")[1:])
+    return sql, partitions
+
+
+def cpu_baseline(sample_universities=1):
+    """The oracle (CPU restatement) on a bounded sample of the same workload, rank 0 only."""
+    from opus_amd import lubm
+    from opus_amd.host import translator as T
+    from oracle import dap_oracle, query_oracle
+    arr, nt = lubm.generate(0, sample_universities, seed=0, ontology=0, degree_pool=1000)
+    ci = lubm.class_index_text(8, 0)
+    t0 = time.perf_counter()
+    ref = dap_oracle.run_dap(arr.tobytes().decode(), ci, 8)
+    t_part = time.perf_counter() - t0
+    ni = {}
+    for u, c in ref["node_index"]:
+        ni.setdefault(u, []).append(c)
+    cidx = T.load_class_index(ci)
+    times = []
+    for name, text in lubm.queries(0).items():
+        tr = T.translate_query(name, text, lambda x: ni.get(x, []), cidx, ref["partition_stat"])
+        qm, parts, _ = query_oracle.parse_translated_file(tr)
+        proc = query_oracle.SqliteProcessor(ref["vp"])
+        proc.preload(parts)
+        proc.execute(qm)  # warm-up, as the reference does for its first query
+        t0 = time.perf_counter()
+        proc.execute(qm)
+        times.append((time.perf_counter() - t0) * 1e3)
+    geo = math.exp(sum(math.log(max(t, 1e-6)) for t in times) / len(times))
+    return {"value": nt / t_part, "unit": "triples/s", "cores": 1, "kind": "port",
+            "sample": "LUBM-%d (%d triples): Python string-level restatement of the partitioner; queries by SQLite" % (sample_universities, nt),
+            "query_geomean_ms": geo}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--universities", type=int, default=100, help="universities per GPU (100 = LUBM-100, ~14 M triples)")
+    ap.add_argument("--partitions", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_COUNT, Engine
+
+    # ---- synthetic input, resident in HBM before anything is timed
+    ontology = 0
+    u0 = rank * args.universities
+    arr, n_triples = lubm.generate(u0, u0 + args.universities, seed=0, ontology=ontology, degree_pool=1000)
+    text = torch.from_numpy(arr).to("cuda:%d" % local_rank)
+    n_bytes = int(arr.size)
+    del arr
+    ci = lubm.class_index_text(args.partitions, ontology)
+    torch.cuda.synchronize()
+    eng = Engine(local_rank)
+
+    def partition():
+        t0 = time.perf_counter()
+        st = eng.partition_device(text.data_ptr(), n_bytes, ci, args.partitions)
+        return time.perf_counter() - t0, st
+
+    _, st = partition()  # sizes the allocator's cache and gives the translator its inputs
+    queries = translated_queries(eng, ci, ontology)
+    qnames = sorted(queries, key=lambda n: int(n[1:-4]))
+    plans = {n: parse_translated(queries[n]) for n in qnames}
+
+    def run_queries(first):
+        times, counts, dev = {}, {}, {}
+        for n in qnames:
+            sql, parts = plans[n]
+            eng.unload_all()                       # unloadTables of the previous query
+            for p in parts:                        # preloadTables: resident in HBM, reported as Time_load by the reference
+                eng.load_table(p)
+            if first and n == qnames[0]:
+                eng.query(sql, DX_QUERY_COUNT).close()   # the reference's one untimed run of the first query
+            t0 = time.perf_counter()
+            r = eng.query(sql, DX_QUERY_COUNT)
+            times[n] = (time.perf_counter() - t0) * 1e3
+            counts[n] = r.count
+            dev[n] = r.device_ms
+            r.close()
+        return times, counts, dev
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        partition()
+        run_queries(first=(w == 0))
+
+    part_s, q_ms, q_dev, stage_ms = [], [], [], []
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        dt, st = partition()
+        part_s.append(dt)
+        stage_ms.append([st.ms_stage[i] for i in range(12)])
+        times, counts, dev = run_queries(first=False)
+        q_ms.append(times)
+        q_dev.append(dev)
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+
+    if world > 1:
+        tt = torch.tensor([elapsed, sum(part_s)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, part_total = tt.tolist()
+        nt = torch.tensor([n_triples], device="cuda", dtype=torch.int64)
+        dist.all_reduce(nt)
+        total_triples = int(nt.item())
+    else:
+        part_total, total_triples = sum(part_s), n_triples
+
+    if rank == 0:
+        med = lambda xs: float(np.median(xs))  # noqa: E731
+        q_med = {n: med([q[n] for q in q_ms]) for n in qnames}
+        q_dev_med = {n: med([q[n] for q in q_dev]) for n in qnames}
+        geo = math.exp(sum(math.log(max(v, 1e-9)) for v in q_med.values()) / len(q_med))
+        geo_dev = math.exp(sum(math.log(max(v, 1e-9)) for v in q_dev_med.values()) / len(q_dev_med))
+        stage_names = [eng.lib.dx_part_stage_name(i).decode() for i in range(12)]
+        stage_avg = {stage_names[i]: float(np.mean([s[i] for s in stage_ms])) for i in range(12) if stage_names[i]}
+        # dominant kernel of the step: the tokenise+hash kernel is the only launch of its stage, so the
+        # hipEvent pair the library records around it (on the library's own stream) is its duration
+        tok_ms = stage_avg["tokenise_hash"]
+        achieved = n_bytes / (tok_ms * 1e-3) / 1e9
+        # algorithmic bytes of the whole partitioner per SURVEY 8(d): text once + R*(24+16) B per triple
+        R = st.n_rows / max(1, st.n_triples)
+        hp1_alg_bytes = n_bytes + st.n_rows * 40
+        out = {
+            "metric": "LUBM Q1-Q14 geo-mean query ms + DAP partitioning triples/sec",
+            "value": total_triples * args.steps / part_total,
+            "unit": "triples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": "LUBM-%d per GPU (%d triples, %.2f GB of N-Triples text per GPU), %d first-level partitions, "
+                                   "13 LUBM queries (Q1-Q12, Q14)" % (args.universities, n_triples, n_bytes / 1e9, args.partitions),
+                       "parallelism": "independent university blocks per GPU, no cross-GPU exchange" if world > 1 else "single GPU"},
+            "partition_ms": med(part_s) * 1e3,
+            "partition_stage_ms": stage_avg,
+            "partition_algorithmic_GBps": hp1_alg_bytes / med(part_s) / 1e9,
+            "replication_factor": R,
+            "query_geomean_ms": geo,
+            "query_geomean_device_ms": geo_dev,
+            "query_ms": q_med,
+            "query_counts": {n: int(counts[n]) for n in qnames},
+            "roofline": {"bound": "hbm", "kernel": "k_tokenise (record -> 3 term spans + 64-bit hashes)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,11 +11,7 @@
 #include "dx_state.h"
 
 namespace dx {
-uint64_t hash_bytes_host(const uint8_t* p, size_t n, uint64_t seed) {
-  TermHash h(seed);
-  for (size_t i = 0; i < n; ++i) h.add(p[i]);
-  return h.finish((uint32_t)n);
-}
+uint64_t hash_bytes_host(const uint8_t* p, size_t n, uint64_t seed) { return hash_bytes(p, n, seed); }
 
 namespace {
 

@@ -9,20 +9,26 @@ namespace dx {
 constexpr int kWave = 64;
 
 // ---- term hash ------------------------------------------------------------------------------
-// Two 32-bit multiplicative streams over the bytes, finalised into one 64-bit word. The same
-// code runs on the host (query constants, class-index entries) and on the device (tokeniser).
-// A hash is only a bucket choice: every dictionary hit is confirmed by a full byte compare, and a
-// true 64-bit collision between different strings makes the build restart with another seed.
+// Two murmur3-style 32-bit lanes fed with the term's bytes four at a time (little-endian words
+// counted from the term's first byte; a final partial word is zero-padded), finalised together with
+// the length into one 64-bit word. The same code runs on the host (query constants, class-index
+// entries) and on the device (tokeniser, lookups). A hash is only a bucket choice: every dictionary
+// hit is confirmed by a full byte compare, and a true 64-bit collision between different strings
+// makes the build restart with another seed.
 struct TermHash {
   uint32_t a, b;
   __host__ __device__ explicit TermHash(uint64_t seed)
-      : a(0x811C9DC5u ^ (uint32_t)seed), b(0x9747B28Cu ^ (uint32_t)(seed >> 32)) {}
-  __host__ __device__ void add(uint8_t c) {
-    a = (a ^ c) * 0x01000193u;
-    b = (b ^ c) * 0x5BD1E995u;
-    b ^= b >> 15;
+      : a(0x9747B28Cu ^ (uint32_t)seed), b(0x85EBCA6Bu ^ (uint32_t)(seed >> 32)) {}
+  static __host__ __device__ inline uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+  __host__ __device__ inline void add_word(uint32_t k) {
+    uint32_t k1 = k * 0xCC9E2D51u;
+    k1 = rotl(k1, 15) * 0x1B873593u;
+    a = rotl(a ^ k1, 13) * 5u + 0xE6546B64u;
+    uint32_t k2 = k * 0x85EBCA77u;
+    k2 = rotl(k2, 13) * 0xC2B2AE3Du;
+    b = rotl(b ^ k2, 17) * 5u + 0x561CCD1Bu;
   }
-  __host__ __device__ uint64_t finish(uint32_t len) const {
+  __host__ __device__ inline uint64_t finish(uint32_t len) const {
     uint64_t h = ((uint64_t)a << 32) | (uint64_t)(b ^ len);
     h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull;
     h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull;
@@ -30,6 +36,20 @@ struct TermHash {
     return h ? h : 1;  // 0 marks an empty dictionary slot
   }
 };
+
+// Hash of n bytes that can only be read one at a time (host strings, the device's slow paths).
+__host__ __device__ inline uint64_t hash_bytes(const uint8_t* p, uint64_t n, uint64_t seed) {
+  TermHash h(seed);
+  uint64_t i = 0;
+  for (; i + 4 <= n; i += 4)
+    h.add_word((uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16) | ((uint32_t)p[i + 3] << 24));
+  if (i < n) {
+    uint32_t k = 0;
+    for (int s = 0; i < n; ++i, s += 8) k |= (uint32_t)p[i] << s;
+    h.add_word(k);
+  }
+  return h.finish((uint32_t)n);
+}
 
 __host__ __device__ inline uint64_t mix64(uint64_t h) {
   h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull;

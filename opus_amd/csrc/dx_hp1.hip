@@ -28,7 +28,7 @@ namespace {
 
 constexpr uint8_t kFlagLiteral = 1, kFlagVertex = 2, kFlagEdge = 4, kFlagNode = 8;
 constexpr int kTypeLen = 49;
-__constant__ char c_rdf_type[kTypeLen + 1] = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>";
+__constant__ __attribute__((aligned(16))) char c_rdf_type[52] = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>";
 
 __device__ __forceinline__ bool is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
 __device__ __forceinline__ bool is_jws(uint8_t c) { return c == ' ' || c == '\t' || c == 0x0B || c == 0x0C; }
@@ -36,104 +36,135 @@ __device__ __forceinline__ bool is_jws(uint8_t c) { return c == ' ' || c == '\t'
 // ---- 1. record starts -----------------------------------------------------------------------------
 // A line starts at byte 0 and after every terminator (LF, CR LF, or a lone CR: Hadoop's LineRecordReader
 // behind sc.textFile); a record is a line that does not start with '#' (Preprocessor.scala:120).
+// The text is cut into 32 KiB tiles. k_line_count counts the records that START in each tile; after a
+// scan of those counts the tokeniser (one block per tile) knows the index of its first record.
 constexpr int LS_THREADS = 256;
-constexpr int LS_ITERS = 8;
-constexpr int LS_TILE = LS_THREADS * 16 * LS_ITERS;  // 32 KiB of text per block
+constexpr int LS_TILE = 32768;
+constexpr int LS_PER_THREAD = LS_TILE / LS_THREADS;  // 128 bytes
 
-template <bool WRITE>
-__global__ void __launch_bounds__(LS_THREADS)
-k_line_starts(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ tile_counts,
-              uint64_t* __restrict__ rec_off, unsigned long long* __restrict__ err) {
-  __shared__ uint32_t lds[8];
-  const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
-  uint32_t run = WRITE ? tile_counts[blockIdx.x] : 0;  // exclusive prefix when writing
-  uint32_t mine = 0;
-  for (int it = 0; it < LS_ITERS; ++it) {
-    const uint64_t i0 = tile0 + (uint64_t)it * (LS_THREADS * 16) + (uint64_t)threadIdx.x * 16;
-    uint8_t c[16];
-    uint32_t mask = 0;
-    if (i0 < n) {
-      if (i0 + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(text + i0);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+// 0x80 in every byte of v that is <= 0x20 (exact, no cross-byte carries)
+__device__ __forceinline__ uint32_t le20_mask(uint32_t v) {
+  const uint32_t t = (v & 0x7F7F7F7Fu) + 0x5F5F5F5Fu;  // bit 7 set iff the low seven bits are >= 0x21
+  return ~(t | v) & 0x80808080u;
+}
+// 0x80 in every byte of v that lies in [0x0A, 0x0D]: LF and CR plus the rare VT / FF
+__device__ __forceinline__ uint32_t eol_candidates(uint32_t v) {
+  const uint32_t lo7 = v & 0x7F7F7F7Fu;
+  const uint32_t gt0d = lo7 + 0x72727272u;  // bit 7 set iff low seven bits >= 0x0E
+  const uint32_t ge0a = lo7 + 0x76767676u;  // bit 7 set iff low seven bits >= 0x0A
+  return ge0a & ~gt0d & ~v & 0x80808080u;
+}
+// Is the byte at offset i (prev = the byte before it) the first byte of a line?
+__device__ __forceinline__ bool line_starts_here(uint8_t prev, uint8_t cur) {
+  return prev == '\n' || (prev == '\r' && cur != '\n');
+}
+
+// Walks the 16 bytes w[0..3] that sit at offset `at` and calls on_start(offset) for every line start at
+// an offset in (at, at + 16] whose line is a record candidate... The byte after a chunk is needed only when
+// the chunk's last byte is a terminator; `next16` supplies it.
+template <typename NextByte, typename OnStart>
+__device__ __forceinline__ void starts_in_chunk(const uint32_t w[4], NextByte next16, OnStart on_start) {
+  uint32_t cand[4] = {eol_candidates(w[0]), eol_candidates(w[1]), eol_candidates(w[2]), eol_candidates(w[3])};
+  if (!(cand[0] | cand[1] | cand[2] | cand[3])) return;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) c[j] = (uint8_t)(w[j >> 2] >> ((j & 3) * 8));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) c[j] = (i0 + j < n) ? text[i0 + j] : (uint8_t)'x';
-      }
-      uint8_t prev = i0 ? text[i0 - 1] : (uint8_t)'\n';
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const uint8_t cur = c[j];
-        const bool start = (i0 + j < n) && (prev == '\n' || (prev == '\r' && cur != '\n'));
-        if (start) {
-          if (is_eol(cur)) atomicMin(err, (unsigned long long)(i0 + j));  // empty line: the reference throws
-          else if (cur != '#') mask |= 1u << j;
-        }
-        prev = cur;
-      }
+  for (int d = 0; d < 4; ++d) {
+    uint32_t m = cand[d];
+    while (m) {
+      const int k = (__ffs((int)m) - 1) >> 3;
+      m &= m - 1;
+      const int j = d * 4 + k;  // byte index of the terminator candidate inside the chunk
+      const uint8_t c = (uint8_t)(w[d] >> (8 * k));
+      if (c != '\n' && c != '\r') continue;
+      const uint8_t nb = (j < 15) ? (uint8_t)(w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) : next16();
+      if (c == '\r' && nb == '\n') continue;  // CR LF: the line starts after the LF
+      on_start(j + 1, nb);
     }
-    const uint32_t cnt = __popc(mask);
-    if (!WRITE) {
-      mine += cnt;
-    } else {
-      uint32_t total;
-      uint32_t pos = run + block_excl_scan_256<uint32_t>(cnt, lds, total);
-      while (mask) {
-        const int j = __ffs(mask) - 1;
-        mask &= mask - 1;
-        rec_off[pos++] = i0 + j;
-      }
-      run += total;
-    }
-  }
-  if (!WRITE) {
-    uint32_t total;
-    (void)block_excl_scan_256<uint32_t>(mine, lds, total);
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
   }
 }
 
+__global__ void __launch_bounds__(LS_THREADS)
+k_line_count(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ tile_counts,
+             unsigned long long* __restrict__ err) {
+  __shared__ uint32_t lds[8];
+  // thread t owns the line starts at offsets [seg0, seg0 + 128); they follow terminators at [seg0 - 1, seg0 + 127)
+  const uint64_t seg0 = (uint64_t)blockIdx.x * LS_TILE + (uint64_t)threadIdx.x * LS_PER_THREAD;
+  uint32_t mine = 0;
+  if (seg0 < n) {
+    auto on_start = [&](uint64_t pos, uint8_t first) {
+      if (pos >= n || pos >= seg0 + LS_PER_THREAD) return;
+      if (is_eol(first)) atomicMin(err, (unsigned long long)pos);  // empty line: the reference throws
+      else if (first != '#') ++mine;
+    };
+    if (seg0 == 0) {
+      on_start(0, text[0]);
+    } else {
+      const uint8_t prev = text[seg0 - 1], cur = text[seg0];
+      if (line_starts_here(prev, cur)) on_start(seg0, cur);
+    }
+    for (int c = 0; c < LS_PER_THREAD; c += 16) {
+      const uint64_t i0 = seg0 + c;
+      if (i0 >= n) break;
+      uint32_t w[4];
+      if (i0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + i0);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+      } else {
+        for (int j = 0; j < 4; ++j) {
+          w[j] = 0x78787878u;
+          for (int k = 0; k < 4; ++k)
+            if (i0 + j * 4 + k < n) w[j] = (w[j] & ~(0xFFu << (8 * k))) | ((uint32_t)text[i0 + j * 4 + k] << (8 * k));
+        }
+      }
+      starts_in_chunk(w, [&]() -> uint8_t { return i0 + 16 < n ? text[i0 + 16] : (uint8_t)'x'; },
+                      [&](int off, uint8_t first) { on_start(i0 + off, first); });
+    }
+  }
+  uint32_t total;
+  (void)block_excl_scan_256<uint32_t>(mine, lds, total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
 // ---- 2. tokenise + hash -------------------------------------------------------------------------------
-// One record per thread. Field split = java.lang.String.split("\\s+", 3) (Preprocessor.scala:121);
-// subject/predicate are trimmed; the object is the third field minus its last two UTF-16 units,
-// trimmed (:122). Lines with fewer than three fields make the reference throw: reported through err.
+// Field split = java.lang.String.split("\\s+", 3) (Preprocessor.scala:121); subject and predicate are
+// trimmed; the object is the third field minus its last two UTF-16 units, trimmed (:122). Lines with
+// fewer than three fields make the reference throw: reported through err.
+struct RecordOut {
+  uint64_t rep[3];   // (byte offset << 24) | length
+  uint64_t hash[3];
+  uint8_t kind;      // 0 object-property triple, 1 rdf:type, 2 literal object
+  bool bad;
+};
+
 __device__ __forceinline__ void trim_range(const uint8_t* t, uint64_t& b, uint64_t& e) {
   while (b < e && t[b] <= 0x20) ++b;
   while (e > b && t[e - 1] <= 0x20) --e;
 }
 __device__ __forceinline__ uint64_t hash_range(const uint8_t* t, uint64_t b, uint64_t e, uint64_t seed) {
-  TermHash h(seed);
-  for (uint64_t i = b; i < e; ++i) h.add(t[i]);
-  return h.finish((uint32_t)(e - b));
+  return hash_bytes(t + b, e - b, seed);
 }
 
-__global__ void __launch_bounds__(256)
-k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
-           uint64_t seed, uint64_t* __restrict__ t_rep /*3*n_rec packed (off,len)*/, uint64_t* __restrict__ t_hash,
-           uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_rec) return;
-  const uint64_t start = rec_off[r];
+// Reference-exact tokeniser of one record read byte by byte from global memory. The fast path below
+// hands a record over whenever it meets anything unusual (control characters, non-ASCII bytes where
+// the last two units are dropped, a line running past the staged window).
+__device__ __noinline__ void tokenise_record_slow(const uint8_t* __restrict__ text, uint64_t n, uint64_t start, uint64_t seed,
+                                                  RecordOut& out) {
   uint64_t p = start;
   uint64_t b[3], e[3];
-  bool bad = false;
+  out.bad = false;
   b[0] = p;
   while (p < n && !is_eol(text[p]) && !is_jws(text[p])) ++p;
   e[0] = p;
-  if (p >= n || is_eol(text[p])) bad = true;
-  if (!bad) {
+  if (p >= n || is_eol(text[p])) out.bad = true;
+  if (!out.bad) {
     while (p < n && is_jws(text[p])) ++p;
     b[1] = p;
     while (p < n && !is_eol(text[p]) && !is_jws(text[p])) ++p;
     e[1] = p;
-    if (p >= n || is_eol(text[p])) bad = true;
+    if (p >= n || is_eol(text[p])) out.bad = true;
   }
-  if (bad) {
-    atomicMin(err, (unsigned long long)start);
-    for (int k = 0; k < 3; ++k) { t_rep[3ull * r + k] = 0; t_hash[3ull * r + k] = 1; }
-    kind[r] = 0;
+  if (out.bad) {
+    for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 1; }
+    out.kind = 0;
     return;
   }
   while (p < n && is_jws(text[p])) ++p;
@@ -146,19 +177,17 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint64_t* __restr
     uint64_t q = e[2] - 1;
     while (q > b[2] && (text[q] & 0xC0) == 0x80) --q;
     const int u = ((text[q] & 0xF8) == 0xF0) ? 2 : 1;
-    if (u > units) { atomicMin(err, (unsigned long long)start); break; }  // would split a surrogate pair
+    if (u > units) { out.bad = true; break; }  // would split a surrogate pair
     units -= u;
     e[2] = q;
   }
   for (int k = 0; k < 3; ++k) trim_range(text, b[k], e[k]);
-  bool too_long = false;
   for (int k = 0; k < 3; ++k) {
     const uint64_t len = e[k] - b[k];
-    if (len >= (1ull << kRepLenBits) || b[k] >= (1ull << (64 - kRepLenBits))) too_long = true;
-    t_rep[3ull * r + k] = (b[k] << kRepLenBits) | (len & ((1ull << kRepLenBits) - 1));
-    t_hash[3ull * r + k] = hash_range(text, b[k], e[k], seed);
+    if (len >= (1ull << kRepLenBits)) out.bad = true;
+    out.rep[k] = (b[k] << kRepLenBits) | (len & ((1ull << kRepLenBits) - 1));
+    out.hash[k] = hash_range(text, b[k], e[k], seed);
   }
-  if (too_long) atomicMin(err, (unsigned long long)start);
   uint8_t kd = 0;
   if (e[1] - b[1] == kTypeLen) {
     bool eq = true;
@@ -166,7 +195,228 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint64_t* __restr
     if (eq) kd = 1;
   }
   if (kd == 0 && e[2] > b[2] && text[b[2]] == '"') kd = 2;
-  kind[r] = kd;
+  out.kind = kd;
+}
+
+// Fast path: one block stages a 32 KiB tile (+ 8 KiB so that lines starting near its end are whole)
+// into LDS with coalesced 16-byte loads, finds the record starts there, and each thread tokenises
+// records out of LDS four bytes at a time (unaligned words via v_alignbyte, delimiter search by SWAR,
+// hashing fused into the scan of subject and predicate).
+constexpr int TK_THREADS = 256;
+constexpr int TK_OVER = 6144;
+constexpr int TK_WIN = LS_TILE + TK_OVER;      // bytes staged per block
+constexpr int TK_PRE = 16;                     // bytes staged before the tile (only the last one is looked at)
+constexpr int TK_MAXREC = LS_TILE / 5 + 2;     // "a b \n" is the shortest record the reference accepts
+
+__device__ __forceinline__ uint32_t lds_word(const uint32_t* win, uint32_t pos) {  // 4 bytes at any byte offset
+  const uint32_t i = pos >> 2;
+  return __builtin_amdgcn_alignbyte(win[i + 1], win[i], pos & 3);
+}
+__device__ __forceinline__ uint8_t lds_byte(const uint32_t* win, uint32_t pos) {
+  return (uint8_t)(win[pos >> 2] >> ((pos & 3) * 8));
+}
+
+// Scans a subject/predicate field starting at pos: returns its end (the first delimiter) and feeds its
+// bytes to h. odd = true when the record needs the slow path. One LDS word is read per four bytes: the
+// upper word of each unaligned read is carried over as the lower word of the next.
+__device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos, uint32_t limit, TermHash& h, bool& odd) {
+  uint32_t i = pos >> 2;
+  const uint32_t sh = pos & 3;
+  uint32_t lo = win[i];
+  for (;;) {
+    if (4 * i + sh + 4 > limit) { odd = true; return 4 * i + sh; }
+    const uint32_t hi = win[i + 1];
+    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    const uint32_t m = le20_mask(v);
+    if (!m) { h.add_word(v); ++i; lo = hi; continue; }
+    const int k = (__ffs((int)m) - 1) >> 3;
+    const uint8_t c = (uint8_t)(v >> (8 * k));
+    if (!(is_jws(c) || is_eol(c))) { odd = true; return 4 * i + sh; }  // control character inside a token
+    if (k) h.add_word(v & ((1u << (8 * k)) - 1u));
+    return 4 * i + sh + k;
+  }
+}
+
+__global__ void __launch_bounds__(TK_THREADS)
+k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/,
+           uint64_t seed, uint64_t type_hash, uint64_t* __restrict__ t_rep /*3*n_rec packed (off,len)*/,
+           uint64_t* __restrict__ t_hash, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 4];
+  __shared__ uint16_t starts[TK_MAXREC];
+  __shared__ uint32_t scan_lds[8];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
+  const uint32_t first_rec = tile_first[blockIdx.x];
+  const uint32_t n_here = tile_first[blockIdx.x + 1] - first_rec;
+  if (n_here == 0) return;  // block-uniform
+  // stage [tile0 - TK_PRE, tile0 + TK_WIN) clipped to the text; bytes outside read as '\n'
+  const uint64_t avail = n - tile0;
+  const uint32_t win_bytes = avail < (uint64_t)TK_WIN ? (uint32_t)avail : (uint32_t)TK_WIN;
+  for (uint32_t c = threadIdx.x * 16; c < TK_PRE + TK_WIN; c += TK_THREADS * 16) {
+    const int64_t g = (int64_t)tile0 - TK_PRE + c;  // global byte offset of this 16-byte chunk
+    uint4 v;
+    if (g >= 0 && (uint64_t)g + 16 <= n) {
+      v = *reinterpret_cast<const uint4*>(text + g);
+    } else {
+      uint32_t w[4];
+      for (int j = 0; j < 4; ++j) {
+        w[j] = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int64_t gi = g + j * 4 + k;
+          const uint8_t ch = (gi >= 0 && (uint64_t)gi < n) ? text[gi] : (uint8_t)'\n';
+          w[j] |= (uint32_t)ch << (8 * k);
+        }
+      }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4*>(&win[c >> 2]) = v;
+  }
+  if (threadIdx.x < 4) win[(TK_PRE + TK_WIN) / 4 + threadIdx.x] = 0x0A0A0A0Au;
+  __syncthreads();
+  // record starts of this tile, in order. Positions are window offsets (tile byte i is at TK_PRE + i).
+  {
+    const uint32_t seg = TK_PRE + threadIdx.x * LS_PER_THREAD;  // thread t owns starts at [seg, seg + 128)
+    const uint32_t seg_tile = threadIdx.x * LS_PER_THREAD;
+    uint32_t cnt = 0;
+    constexpr uint32_t kMaxFound = 28;  // 128 bytes hold at most 25 records of three fields
+    uint16_t found[kMaxFound];
+    auto on_start = [&](uint32_t pos, uint8_t first) {  // pos = window offset
+      const uint32_t tpos = pos - TK_PRE;
+      if (tpos >= win_bytes || tpos >= seg_tile + LS_PER_THREAD) return;
+      if (!is_eol(first) && first != '#') {
+        if (cnt < kMaxFound) found[cnt] = (uint16_t)pos;
+        ++cnt;
+      }
+    };
+    if (seg_tile < win_bytes) {
+      const uint8_t prev = lds_byte(win, seg - 1), cur = lds_byte(win, seg);
+      if (line_starts_here(prev, cur)) on_start(seg, cur);
+      for (uint32_t c = 0; c < (uint32_t)LS_PER_THREAD; c += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&win[(seg + c) >> 2]);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        starts_in_chunk(w, [&]() -> uint8_t { return lds_byte(win, seg + c + 16); },
+                        [&](int off, uint8_t first) { on_start(seg + c + off, first); });
+      }
+    }
+    uint32_t total;
+    uint32_t at = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);
+    // Lines too short to hold three fields can be denser than the lists allow for. They are errors in
+    // any case: flag the tile, give its records harmless outputs and stop.
+    const bool dense = __syncthreads_or(cnt > kMaxFound || total > (uint32_t)TK_MAXREC || total != n_here);
+    if (dense) {
+      if (threadIdx.x == 0) atomicMin(err, (unsigned long long)tile0);
+      for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
+        const uint64_t r = (uint64_t)first_rec + lr;
+        for (int k = 0; k < 3; ++k) { t_rep[3 * r + k] = 0; t_hash[3 * r + k] = 1; }
+        kind[r] = 0;
+      }
+      return;
+    }
+    for (uint32_t i = 0; i < cnt; ++i) starts[at + i] = found[i];
+  }
+  __syncthreads();
+  const uint32_t limit = TK_PRE + win_bytes;           // one past the last staged text byte
+  const bool window_is_eof = tile0 + win_bytes >= n;   // staged window reaches the end of the text
+  for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
+    const uint32_t p0 = starts[lr];
+    const uint64_t gstart = tile0 + (p0 - TK_PRE);
+    RecordOut out;
+    bool odd = false;
+    out.bad = false;
+    uint32_t b[3], e[3];
+    // subject
+    TermHash hs(seed), hp(seed), ho(seed);
+    b[0] = p0;
+    e[0] = scan_token(win, p0, limit + 4, hs, odd);
+    uint32_t p = e[0];
+    if (!odd) {
+      if (is_eol(lds_byte(win, p)) || p >= limit) { out.bad = !(p >= limit && !window_is_eof); odd = !out.bad; }
+    }
+    if (!odd && !out.bad) {
+      while (p < limit && is_jws(lds_byte(win, p))) ++p;
+      b[1] = p;
+      e[1] = scan_token(win, p, limit + 4, hp, odd);
+      p = e[1];
+      if (!odd && (is_eol(lds_byte(win, p)) || p >= limit)) { out.bad = !(p >= limit && !window_is_eof); odd = !out.bad; }
+    }
+    if (!odd && !out.bad) {
+      while (p < limit && is_jws(lds_byte(win, p))) ++p;
+      b[2] = p;
+      // end of line
+      uint32_t q = p;
+      bool found = false;
+      {
+        uint32_t i = q >> 2;
+        const uint32_t sh = q & 3;
+        uint32_t lo = win[i];
+        while (!found) {
+          if (q >= limit) break;
+          const uint32_t hi = win[i + 1];
+          const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+          uint32_t m = eol_candidates(v);
+          while (m) {
+            const int k = (__ffs((int)m) - 1) >> 3;
+            m &= m - 1;
+            if (is_eol((uint8_t)(v >> (8 * k)))) { q += k; found = true; break; }
+          }
+          if (!found) { q += 4; ++i; lo = hi; }
+        }
+      }
+      if (!found) { q = limit; if (!window_is_eof) odd = true; }  // the line runs past the staged window
+      if (q > limit) q = limit;
+      e[2] = q;
+      if (!odd) {
+        // dropRight(2) then trim; non-ASCII bytes at the cut go to the slow path
+        if (e[2] - b[2] >= 2) {
+          if ((lds_byte(win, e[2] - 1) | lds_byte(win, e[2] - 2)) & 0x80) odd = true;
+          e[2] -= 2;
+        } else {
+          e[2] = b[2];
+        }
+        while (e[2] > b[2] && lds_byte(win, e[2] - 1) <= 0x20) --e[2];
+        while (b[2] < e[2] && lds_byte(win, b[2]) <= 0x20) ++b[2];
+      }
+    }
+    if (odd) {
+      tokenise_record_slow(text, n, gstart, seed, out);
+    } else if (!out.bad) {
+      // object hash
+      {
+        uint32_t q = b[2], i = q >> 2;
+        const uint32_t sh = q & 3;
+        uint32_t lo = win[i];
+        for (; q + 4 <= e[2]; q += 4, ++i) {
+          const uint32_t hi = win[i + 1];
+          ho.add_word(__builtin_amdgcn_alignbyte(hi, lo, sh));
+          lo = hi;
+        }
+        if (q < e[2]) ho.add_word(__builtin_amdgcn_alignbyte(win[i + 1], lo, sh) & ((1u << (8 * (e[2] - q))) - 1u));
+      }
+      const uint32_t len[3] = {e[0] - b[0], e[1] - b[1], e[2] - b[2]};
+      out.hash[0] = hs.finish(len[0]);
+      out.hash[1] = hp.finish(len[1]);
+      out.hash[2] = ho.finish(len[2]);
+      for (int k = 0; k < 3; ++k) out.rep[k] = ((tile0 + (b[k] - TK_PRE)) << kRepLenBits) | len[k];
+      uint8_t kd = 0;
+      if (len[1] == kTypeLen && out.hash[1] == type_hash) {  // hash first, then the proof, a word at a time
+        const uint32_t* tw = reinterpret_cast<const uint32_t*>(c_rdf_type);
+        bool eq = true;
+#pragma unroll
+        for (int i = 0; i < kTypeLen / 4; ++i) eq &= lds_word(win, b[1] + 4 * i) == tw[i];
+        eq &= lds_byte(win, b[1] + kTypeLen - 1) == (uint8_t)c_rdf_type[kTypeLen - 1];
+        if (eq) kd = 1;
+      }
+      if (kd == 0 && len[2] && lds_byte(win, b[2]) == '"') kd = 2;
+      out.kind = kd;
+    }
+    const uint64_t r = (uint64_t)first_rec + lr;
+    if (out.bad) {
+      atomicMin(err, (unsigned long long)gstart);
+      for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 1; }
+      out.kind = 0;
+    }
+    for (int k = 0; k < 3; ++k) { t_rep[3 * r + k] = out.rep[k]; t_hash[3 * r + k] = out.hash[k]; }
+    kind[r] = out.kind;
+  }
 }
 
 // ---- 3. dictionary ---------------------------------------------------------------------------------
@@ -212,8 +462,14 @@ k_dict_verify(const uint8_t* __restrict__ text, const uint64_t* __restrict__ t_r
   if (same) {
     const uint8_t* a = text + (mine >> kRepLenBits);
     const uint8_t* b = text + (r >> kRepLenBits);
-    for (uint64_t j = 0; j < lm; ++j)
-      if (a[j] != b[j]) { same = false; break; }
+    uint64_t j = 0;
+    for (; same && j + 8 <= lm; j += 8) {  // gfx950 serves unaligned 8-byte global loads
+      uint64_t x, y;
+      __builtin_memcpy(&x, a + j, 8);
+      __builtin_memcpy(&y, b + j, 8);
+      same = x == y;
+    }
+    for (; same && j < lm; ++j) same = a[j] == b[j];
   }
   if (!same) *collision = 1;
 }
@@ -366,11 +622,13 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
     mask[i] = m;
     node_flag[i] = nf;
   }
-  uq = wave_reduce_u32(uq);
-  ed = wave_reduce_u32(ed);
-  if ((threadIdx.x & 63) == 0) {
-    if (uq) atomicAdd(&counters[0], (unsigned long long)uq);
-    if (ed) atomicAdd(&counters[1], (unsigned long long)ed);
+  __shared__ uint32_t lds[8];
+  uint32_t tu, te;
+  (void)block_excl_scan_256<uint32_t>(uq, lds, tu);
+  (void)block_excl_scan_256<uint32_t>(ed, lds, te);
+  if (threadIdx.x == 0) {  // one pair of atomics per block: thousands of waves hitting one word serialise
+    if (tu) atomicAdd(&counters[0], (unsigned long long)tu);
+    if (te) atomicAdd(&counters[1], (unsigned long long)te);
   }
 }
 
@@ -631,14 +889,13 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint32_t> d_total(pool, 4);
   uint32_t n_rec = 0;
   if (n_bytes) {
-    hipLaunchKernelGGL(k_line_starts<false>, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, tile_counts.p, nullptr, err.p);
-    exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, ntiles, d_total.p, s);
+    DX_HIP(hipMemsetAsync(tile_counts.p + ntiles, 0, 4, s));
+    hipLaunchKernelGGL(k_line_count, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, tile_counts.p, err.p);
+    exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, (size_t)ntiles + 1, d_total.p, s);
     DX_HIP(hipMemcpyAsync(&n_rec, d_total.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
   }
   st.n_triples = n_rec;
-  DevBuf<uint64_t> rec_off(pool, n_rec);
-  if (n_rec) hipLaunchKernelGGL(k_line_starts<true>, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, tile_counts.p, rec_off.p, err.p);
   tm.mark();
 
   const uint64_t n_occ = 3ull * n_rec;
@@ -662,8 +919,9 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2));
     DX_HIP(hipEventRecord(e0, s));
     if (n_rec)
-      hipLaunchKernelGGL(k_tokenise, dim3(blocks(n_rec)), dim3(256), 0, s, text, n_bytes, rec_off.p, n_rec, seed, t_rep.p, t_hash.p,
-                         kind.p, err.p);
+      hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, tile_counts.p, seed,
+                         hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), t_rep.p,
+                         t_hash.p, kind.p, err.p);
     DX_HIP(hipEventRecord(e1, s));
     // ---- 3. dictionary
     DX_HIP(hipMemsetAsync(keys.p, 0, cap * 8, s));
@@ -716,7 +974,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   d.ht_ids = std::move(slot_id);
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
-  t_hash.reset(); t_slot.reset(); first.reset(); first_scan.reset(); rep.reset(); rec_off.reset();
+  t_hash.reset(); t_slot.reset(); first.reset(); first_scan.reset(); rep.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);

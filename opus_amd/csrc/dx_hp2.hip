@@ -26,7 +26,7 @@ namespace {
 
 constexpr int MAXC = 10;
 constexpr int MAXSTEPS = 30;
-constexpr int kConstBytes = 3072;
+constexpr int kConstBytes = 2560;
 constexpr int kMaxConsts = 32;
 
 struct RelDev {
@@ -54,6 +54,7 @@ struct ConstArgs {
   char bytes[kConstBytes];
   uint32_t off[kMaxConsts + 1];
   long long preset[kMaxConsts];  // LLONG_MIN = look the string up, anything else = the id to use
+  uint64_t hash[kMaxConsts];     // term hash of the string, computed on the host
   int n;
 };
 
@@ -68,9 +69,7 @@ k_resolve_consts(ConstArgs ca, uint64_t seed, const uint64_t* __restrict__ keys,
   if (i >= ca.n) return;
   if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) { out[i] = ca.preset[i]; return; }
   const uint32_t b = ca.off[i], e = ca.off[i + 1];
-  TermHash th(seed);
-  for (uint32_t j = b; j < e; ++j) th.add((uint8_t)ca.bytes[j]);
-  const uint64_t h = th.finish(e - b);
+  const uint64_t h = ca.hash[i];
   uint64_t slot = h & mask;
   int64_t res = -1;
   for (;;) {
@@ -414,8 +413,9 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
   for (int i = 0; i < ca.n; ++i) {
     ca.off[i] = off;
     ca.preset[i] = plan.const_preset[i];
-    if (off + plan.const_str[i].size() > (size_t)kConstBytes) throw DxError(DX_E_UNSUPPORTED, "SQL: constants exceed 3 KiB in total");
+    if (off + plan.const_str[i].size() > (size_t)kConstBytes) throw DxError(DX_E_UNSUPPORTED, "SQL: constants exceed 2.5 KiB in total");
     memcpy(ca.bytes + off, plan.const_str[i].data(), plan.const_str[i].size());
+    ca.hash[i] = hash_bytes((const uint8_t*)plan.const_str[i].data(), plan.const_str[i].size(), ctx->dict.seed);
     off += (uint32_t)plan.const_str[i].size();
   }
   ca.off[ca.n] = off;
