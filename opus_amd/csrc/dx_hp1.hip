@@ -36,7 +36,7 @@ __device__ __forceinline__ bool is_jws(uint8_t c) { return c == ' ' || c == '\t'
 // ---- 1. record starts -----------------------------------------------------------------------------
 // A line starts at byte 0 and after every terminator (LF, CR LF, or a lone CR: Hadoop's LineRecordReader
 // behind sc.textFile); a record is a line that does not start with '#' (Preprocessor.scala:120).
-// The text is cut into 32 KiB tiles. k_line_count counts the records that START in each tile; after a
+// The text is cut into 32 KiB tiles. k_line_scan counts the records that START in each tile; after a
 // scan of those counts the tokeniser (one block per tile) knows the index of its first record.
 constexpr int LS_THREADS = 256;
 constexpr int LS_TILE = 32768;
@@ -54,70 +54,83 @@ __device__ __forceinline__ uint32_t eol_candidates(uint32_t v) {
   const uint32_t ge0a = lo7 + 0x76767676u;  // bit 7 set iff low seven bits >= 0x0A
   return ge0a & ~gt0d & ~v & 0x80808080u;
 }
+// 0x80 in every byte of v equal to c (exact)
+__device__ __forceinline__ uint32_t eq_mask(uint32_t v, uint32_t c4) {
+  const uint32_t x = v ^ c4;
+  return ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) | 0x7F7F7F7Fu);
+}
+// the four 0x80 flags of a word -> 4 bits
+__device__ __forceinline__ uint32_t flags_to_nibble(uint32_t f) {
+  const uint32_t y = f >> 7;
+  return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
+}
 // Is the byte at offset i (prev = the byte before it) the first byte of a line?
 __device__ __forceinline__ bool line_starts_here(uint8_t prev, uint8_t cur) {
   return prev == '\n' || (prev == '\r' && cur != '\n');
 }
 
-// Walks the 16 bytes w[0..3] that sit at offset `at` and calls on_start(offset) for every line start at
-// an offset in (at, at + 16] whose line is a record candidate... The byte after a chunk is needed only when
-// the chunk's last byte is a terminator; `next16` supplies it.
-template <typename NextByte, typename OnStart>
-__device__ __forceinline__ void starts_in_chunk(const uint32_t w[4], NextByte next16, OnStart on_start) {
-  uint32_t cand[4] = {eol_candidates(w[0]), eol_candidates(w[1]), eol_candidates(w[2]), eol_candidates(w[3])};
-  if (!(cand[0] | cand[1] | cand[2] | cand[3])) return;
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    uint32_t m = cand[d];
-    while (m) {
-      const int k = (__ffs((int)m) - 1) >> 3;
-      m &= m - 1;
-      const int j = d * 4 + k;  // byte index of the terminator candidate inside the chunk
-      const uint8_t c = (uint8_t)(w[d] >> (8 * k));
-      if (c != '\n' && c != '\r') continue;
-      const uint8_t nb = (j < 15) ? (uint8_t)(w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) : next16();
-      if (c == '\r' && nb == '\n') continue;  // CR LF: the line starts after the LF
-      on_start(j + 1, nb);
-    }
-  }
-}
-
+// One pass over the text, branch-free SWAR on 16 bytes per lane: writes for every 16-byte chunk the
+// 16-bit mask of the bytes that start a record, and per 32 KiB tile the number of records starting in
+// it. With T = terminator flags (LF | CR) and H = '#' flags, a byte starts a record iff the byte before
+// it is a terminator and it is itself neither a terminator nor '#':  S = (T shifted by one byte) & ~(T | H).
+// (CR LF: the LF is a terminator, so it is not a start, and the byte after it is.) A start that is
+// itself a terminator is an empty line, on which the reference throws.
 __global__ void __launch_bounds__(LS_THREADS)
-k_line_count(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ tile_counts,
-             unsigned long long* __restrict__ err) {
+k_line_scan(const uint8_t* __restrict__ text, uint64_t n, uint16_t* __restrict__ chunk_mask, uint32_t* __restrict__ tile_counts,
+            unsigned long long* __restrict__ err) {
   __shared__ uint32_t lds[8];
-  // thread t owns the line starts at offsets [seg0, seg0 + 128); they follow terminators at [seg0 - 1, seg0 + 127)
-  const uint64_t seg0 = (uint64_t)blockIdx.x * LS_TILE + (uint64_t)threadIdx.x * LS_PER_THREAD;
+  const int lane = threadIdx.x & 63;
   uint32_t mine = 0;
-  if (seg0 < n) {
-    auto on_start = [&](uint64_t pos, uint8_t first) {
-      if (pos >= n || pos >= seg0 + LS_PER_THREAD) return;
-      if (is_eol(first)) atomicMin(err, (unsigned long long)pos);  // empty line: the reference throws
-      else if (first != '#') ++mine;
-    };
-    if (seg0 == 0) {
-      on_start(0, text[0]);
-    } else {
-      const uint8_t prev = text[seg0 - 1], cur = text[seg0];
-      if (line_starts_here(prev, cur)) on_start(seg0, cur);
+  const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
+#pragma unroll 2
+  for (int it = 0; it < LS_TILE / (LS_THREADS * 16); ++it) {
+    const uint64_t i0 = tile0 + (uint64_t)it * (LS_THREADS * 16) + (uint64_t)threadIdx.x * 16;
+    uint32_t w[4] = {0x78787878u, 0x78787878u, 0x78787878u, 0x78787878u};
+    if (i0 + 16 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(text + i0);
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else if (i0 < n) {
+      for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < 4; ++k)
+          if (i0 + j * 4 + k < n) w[j] = (w[j] & ~(0xFFu << (8 * k))) | ((uint32_t)text[i0 + j * 4 + k] << (8 * k));
     }
-    for (int c = 0; c < LS_PER_THREAD; c += 16) {
-      const uint64_t i0 = seg0 + c;
-      if (i0 >= n) break;
-      uint32_t w[4];
-      if (i0 + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(text + i0);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-      } else {
-        for (int j = 0; j < 4; ++j) {
-          w[j] = 0x78787878u;
-          for (int k = 0; k < 4; ++k)
-            if (i0 + j * 4 + k < n) w[j] = (w[j] & ~(0xFFu << (8 * k))) | ((uint32_t)text[i0 + j * 4 + k] << (8 * k));
-        }
-      }
-      starts_in_chunk(w, [&]() -> uint8_t { return i0 + 16 < n ? text[i0 + 16] : (uint8_t)'x'; },
-                      [&](int off, uint8_t first) { on_start(i0 + off, first); });
+    uint32_t L[4], R[4], T[4], H[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      L[d] = eq_mask(w[d], 0x0A0A0A0Au);
+      R[d] = eq_mask(w[d], 0x0D0D0D0Du);
+      H[d] = eq_mask(w[d], 0x23232323u);
+      T[d] = L[d] | R[d];
     }
+    // terminator flag of the byte before this chunk: the previous lane's last byte, or a load at wave edges
+    uint32_t tin = __shfl_up(T[3], 1, 64);
+    uint32_t lin = __shfl_up(L[3], 1, 64);
+    if (lane == 0) {
+      const uint8_t pb = i0 == 0 ? (uint8_t)'\n' : (i0 - 1 < n ? text[i0 - 1] : (uint8_t)'x');
+      tin = (pb == '\n' || pb == '\r') ? 0x80000000u : 0u;
+      lin = pb == '\n' ? 0x80000000u : 0u;
+    }
+    uint32_t S[4], E[4];
+    uint32_t tp = tin, lp = lin;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);  // flags moved up by one byte, carry from the word before
+      const uint32_t Lp = __builtin_amdgcn_alignbit(L[d], lp, 24);
+      S[d] = Tp & ~(T[d] | H[d]);
+      E[d] = (Lp & T[d]) | ((Tp & ~Lp) & R[d]);  // LF then terminator, or CR then CR
+      tp = T[d];
+      lp = L[d];
+    }
+    uint32_t m16 = flags_to_nibble(S[0]) | (flags_to_nibble(S[1]) << 4) | (flags_to_nibble(S[2]) << 8) | (flags_to_nibble(S[3]) << 12);
+    uint32_t e16 = flags_to_nibble(E[0]) | (flags_to_nibble(E[1]) << 4) | (flags_to_nibble(E[2]) << 8) | (flags_to_nibble(E[3]) << 12);
+    if (i0 + 16 > n) {  // bytes past the end of the text start nothing
+      const uint32_t keep = i0 < n ? ((1u << (uint32_t)(n - i0)) - 1u) : 0u;
+      m16 &= keep;
+      e16 &= keep;
+    }
+    if (e16) atomicMin(err, (unsigned long long)(i0 + __ffs((int)e16) - 1));
+    chunk_mask[i0 >> 4] = (uint16_t)m16;  // every chunk of every tile, so the tokeniser never reads an unwritten mask
+    mine += __popc(m16);
   }
   uint32_t total;
   (void)block_excl_scan_256<uint32_t>(mine, lds, total);
@@ -238,9 +251,9 @@ __device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos
 }
 
 __global__ void __launch_bounds__(TK_THREADS)
-k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/,
-           uint64_t seed, uint64_t type_hash, uint64_t* __restrict__ t_rep /*3*n_rec packed (off,len)*/,
-           uint64_t* __restrict__ t_hash, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
+k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask,
+           const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash, uint64_t n_rec,
+           uint64_t* __restrict__ t_rep /*[field][record]: (offset << 24) | length*/, uint64_t* __restrict__ t_hash /*[field][record]*/, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err, int exp_mode) {
   __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 4];
   __shared__ uint16_t starts[TK_MAXREC];
   __shared__ uint32_t scan_lds[8];
@@ -251,69 +264,91 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
   // stage [tile0 - TK_PRE, tile0 + TK_WIN) clipped to the text; bytes outside read as '\n'
   const uint64_t avail = n - tile0;
   const uint32_t win_bytes = avail < (uint64_t)TK_WIN ? (uint32_t)avail : (uint32_t)TK_WIN;
-  for (uint32_t c = threadIdx.x * 16; c < TK_PRE + TK_WIN; c += TK_THREADS * 16) {
-    const int64_t g = (int64_t)tile0 - TK_PRE + c;  // global byte offset of this 16-byte chunk
-    uint4 v;
-    if (g >= 0 && (uint64_t)g + 16 <= n) {
-      v = *reinterpret_cast<const uint4*>(text + g);
-    } else {
-      uint32_t w[4];
-      for (int j = 0; j < 4; ++j) {
-        w[j] = 0;
-        for (int k = 0; k < 4; ++k) {
-          const int64_t gi = g + j * 4 + k;
-          const uint8_t ch = (gi >= 0 && (uint64_t)gi < n) ? text[gi] : (uint8_t)'\n';
-          w[j] |= (uint32_t)ch << (8 * k);
+  // LDS-DMA: every wave-instruction moves 64 x 16 contiguous bytes straight into the window (no VGPR
+  // staging, all copies of a wave in flight at once). Only the spans touching the ends of the text are
+  // assembled by hand.
+  {
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    constexpr uint32_t kStageBytes = TK_PRE + TK_WIN;
+#pragma unroll
+    for (uint32_t it = 0; it < (kStageBytes + TK_THREADS * 16 - 1) / (TK_THREADS * 16); ++it) {
+      const uint32_t wave_c = it * (TK_THREADS * 16) + wv * 1024;  // window offset of this wave's 1 KiB span
+      if (wave_c >= kStageBytes) continue;
+      const int64_t wave_g = (int64_t)tile0 - TK_PRE + wave_c;
+      const uint32_t c = wave_c + ln * 16;
+      if (wave_g >= 0 && (uint64_t)wave_g + 1024 <= n && wave_c + 1024 <= kStageBytes) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(text + wave_g + ln * 16),
+                                         (__attribute__((address_space(3))) void*)&win[wave_c >> 2], 16, 0, 0);
+      } else if (c < kStageBytes) {
+        const int64_t g = wave_g + ln * 16;
+        uint32_t w[4];
+        for (int j = 0; j < 4; ++j) {
+          w[j] = 0;
+          for (int k = 0; k < 4; ++k) {
+            const int64_t gi = g + j * 4 + k;
+            const uint8_t ch = (gi >= 0 && (uint64_t)gi < n) ? text[gi] : (uint8_t)'\n';
+            w[j] |= (uint32_t)ch << (8 * k);
+          }
         }
+        *reinterpret_cast<uint4*>(&win[c >> 2]) = make_uint4(w[0], w[1], w[2], w[3]);
       }
-      v = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    *reinterpret_cast<uint4*>(&win[c >> 2]) = v;
   }
   if (threadIdx.x < 4) win[(TK_PRE + TK_WIN) / 4 + threadIdx.x] = 0x0A0A0A0Au;
+  __builtin_amdgcn_s_waitcnt(0);  // the DMA copies count on vmcnt
   __syncthreads();
+  if (exp_mode == 2) {  // timing experiment: staging only
+    for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
+      const uint64_t r = (uint64_t)first_rec + lr;
+      for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_hash[k * n_rec + r] = 1; }
+      kind[r] = (uint8_t)(win[lr & 1023] >> 31);
+    }
+    return;
+  }
   // record starts of this tile, in order. Positions are window offsets (tile byte i is at TK_PRE + i).
   {
     const uint32_t seg = TK_PRE + threadIdx.x * LS_PER_THREAD;  // thread t owns starts at [seg, seg + 128)
     const uint32_t seg_tile = threadIdx.x * LS_PER_THREAD;
     uint32_t cnt = 0;
-    constexpr uint32_t kMaxFound = 28;  // 128 bytes hold at most 25 records of three fields
-    uint16_t found[kMaxFound];
-    auto on_start = [&](uint32_t pos, uint8_t first) {  // pos = window offset
-      const uint32_t tpos = pos - TK_PRE;
-      if (tpos >= win_bytes || tpos >= seg_tile + LS_PER_THREAD) return;
-      if (!is_eol(first) && first != '#') {
-        if (cnt < kMaxFound) found[cnt] = (uint16_t)pos;
-        ++cnt;
-      }
-    };
+    uint32_t smask[4] = {0, 0, 0, 0};  // bit i of the 128: a record starts at byte i of this thread's segment
     if (seg_tile < win_bytes) {
-      const uint8_t prev = lds_byte(win, seg - 1), cur = lds_byte(win, seg);
-      if (line_starts_here(prev, cur)) on_start(seg, cur);
-      for (uint32_t c = 0; c < (uint32_t)LS_PER_THREAD; c += 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&win[(seg + c) >> 2]);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        starts_in_chunk(w, [&]() -> uint8_t { return lds_byte(win, seg + c + 16); },
-                        [&](int off, uint8_t first) { on_start(seg + c + off, first); });
-      }
+      const uint4 mv = *reinterpret_cast<const uint4*>(chunk_mask + ((tile0 + seg_tile) >> 4));  // 8 chunk masks = 128 bits
+      smask[0] = mv.x; smask[1] = mv.y; smask[2] = mv.z; smask[3] = mv.w;
     }
+    cnt = __popc(smask[0]) + __popc(smask[1]) + __popc(smask[2]) + __popc(smask[3]);
     uint32_t total;
     uint32_t at = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);
     // Lines too short to hold three fields can be denser than the lists allow for. They are errors in
     // any case: flag the tile, give its records harmless outputs and stop.
-    const bool dense = __syncthreads_or(cnt > kMaxFound || total > (uint32_t)TK_MAXREC || total != n_here);
+    const bool dense = __syncthreads_or(total > (uint32_t)TK_MAXREC || total != n_here);
     if (dense) {
       if (threadIdx.x == 0) atomicMin(err, (unsigned long long)tile0);
       for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
         const uint64_t r = (uint64_t)first_rec + lr;
-        for (int k = 0; k < 3; ++k) { t_rep[3 * r + k] = 0; t_hash[3 * r + k] = 1; }
+        for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_hash[k * n_rec + r] = 1; }
         kind[r] = 0;
       }
       return;
     }
-    for (uint32_t i = 0; i < cnt; ++i) starts[at + i] = found[i];
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+      uint32_t m = smask[wd];
+      while (m) {
+        const int bit = __ffs((int)m) - 1;
+        m &= m - 1;
+        starts[at++] = (uint16_t)(seg + wd * 32 + bit);
+      }
+    }
   }
   __syncthreads();
+  if (exp_mode == 1) {  // timing experiment: staging and start detection only, harmless outputs
+    for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
+      const uint64_t r = (uint64_t)first_rec + lr;
+      for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_hash[k * n_rec + r] = 1; }
+      kind[r] = 0;
+    }
+    return;
+  }
   const uint32_t limit = TK_PRE + win_bytes;           // one past the last staged text byte
   const bool window_is_eof = tile0 + win_bytes >= n;   // staged window reaches the end of the text
   for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
@@ -414,86 +449,127 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restr
       for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 1; }
       out.kind = 0;
     }
-    for (int k = 0; k < 3; ++k) { t_rep[3 * r + k] = out.rep[k]; t_hash[3 * r + k] = out.hash[k]; }
+    for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = out.rep[k]; t_hash[k * n_rec + r] = out.hash[k]; }  // field-major: coalesced
     kind[r] = out.kind;
   }
 }
 
 // ---- 3. dictionary ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t dict_find_or_claim(uint64_t* keys, uint64_t mask, uint64_t h) {
-  uint64_t slot = h & mask;
-  for (;;) {
-    uint64_t cur = keys[slot];
-    if (cur == h) break;
-    if (cur == 0) {
-      cur = atomicCAS((unsigned long long*)&keys[slot], 0ull, (unsigned long long)h);
-      if (cur == 0 || cur == h) break;
-    }
-    slot = (slot + 1) & mask;
-  }
-  return (uint32_t)slot;
+constexpr uint32_t kMaxProbes = 1u << 14;  // a longer chain means the table is too full: the build restarts larger
+
+__global__ void __launch_bounds__(256) k_ht_clear(DictSlot* __restrict__ ht, uint64_t cap) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
+    *reinterpret_cast<uint4*>(&ht[i]) = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
 // Every occurrence claims / finds the slot of its hash and lowers the slot's representative to the
 // smallest (offset, length) word, i.e. the first occurrence in the text: ids do not depend on timing.
+// Occurrences are laid out field-major (all subjects, all predicates, all objects, each in text
+// order), so a run of records with one subject is a run of equal hashes in neighbouring lanes: only the
+// first lane of a run goes to memory, the rest of the run (later in the text, so never the minimum)
+// takes its slot over a shuffle.
 __global__ void __launch_bounds__(256)
 k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ t_rep, uint64_t n_occ,
-              uint64_t* __restrict__ keys, uint64_t* __restrict__ rep, uint64_t mask, uint32_t* __restrict__ t_slot) {
+              DictSlot* __restrict__ ht, uint64_t mask, uint32_t* __restrict__ t_slot, uint32_t* __restrict__ overflow) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_occ) return;
-  const uint32_t slot = dict_find_or_claim(keys, mask, t_hash[i]);
-  const uint64_t mine = t_rep[i];
-  if (rep[slot] > mine) atomicMin((unsigned long long*)&rep[slot], (unsigned long long)mine);
-  t_slot[i] = slot;
+  const int lane = threadIdx.x & 63;
+  const bool valid = i < n_occ;
+  const uint64_t h = valid ? t_hash[i] : 0, mine = valid ? t_rep[i] : ~0ull;
+  const uint64_t h_left = __shfl_up(h, 1, 64);
+  const bool leader = valid && (lane == 0 || h_left != h);
+  uint64_t slot = h & mask;
+  if (leader) {
+    uint32_t probes = 0;
+    for (; probes < kMaxProbes; ++probes) {
+      // key and representative share one 16-byte slot: one load answers "is this my slot" and "am I earlier"
+      const uint4 sv = *reinterpret_cast<const uint4*>(&ht[slot]);
+      uint64_t cur = ((uint64_t)sv.y << 32) | sv.x;
+      if (cur == 0) {
+        cur = atomicCAS((unsigned long long*)&ht[slot].key, 0ull, (unsigned long long)h);
+        if (cur == 0 || cur == h) {
+          atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+          break;
+        }
+      } else if (cur == h) {
+        const uint64_t r = ((uint64_t)sv.w << 32) | sv.z;
+        if (r > mine) atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+    if (probes == kMaxProbes) { *overflow = 1; slot = 0; }
+  }
+  const uint64_t leaders = __ballot(leader);
+  const uint64_t at_or_below = leaders & (~0ull >> (63 - lane));
+  const int src = at_or_below ? 63 - __clzll((long long)at_or_below) : lane;
+  const uint32_t run_slot = __shfl((uint32_t)slot, src, 64);
+  if (valid) t_slot[i] = run_slot;
 }
 
 // first[i] = 1 when occurrence i is its slot's representative; any occurrence whose bytes differ from
 // the representative's proves a 64-bit collision between different strings.
 __global__ void __launch_bounds__(256)
 k_dict_verify(const uint8_t* __restrict__ text, const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot,
-              uint64_t n_occ, const uint64_t* __restrict__ rep, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
+              uint64_t n_occ, const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_occ) return;
-  const uint64_t mine = t_rep[i], r = rep[t_slot[i]];
+  const uint64_t mine = t_rep[i], r = ht[t_slot[i]].val;
   if (mine == r) { first[i] = 1; return; }
   first[i] = 0;
   const uint64_t lm = mine & ((1ull << kRepLenBits) - 1), lr = r & ((1ull << kRepLenBits) - 1);
-  bool same = lm == lr;
-  if (same) {
+  uint64_t diff = lm ^ lr;
+  if (!diff) {
     const uint8_t* a = text + (mine >> kRepLenBits);
     const uint8_t* b = text + (r >> kRepLenBits);
-    uint64_t j = 0;
-    for (; same && j + 8 <= lm; j += 8) {  // gfx950 serves unaligned 8-byte global loads
-      uint64_t x, y;
-      __builtin_memcpy(&x, a + j, 8);
-      __builtin_memcpy(&y, b + j, 8);
-      same = x == y;
+    // No early exit (a mismatch practically never happens, and independent loads pipeline) and no byte
+    // tail: the last load of each width overlaps the one before it. gfx950 serves unaligned wide loads.
+    auto d16 = [&](uint64_t off) {
+      uint4 x, y;
+      __builtin_memcpy(&x, a + off, 16);
+      __builtin_memcpy(&y, b + off, 16);
+      diff |= (uint64_t)((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w));
+    };
+    if (lm >= 16) {
+      for (uint64_t j = 0; j + 16 < lm; j += 16) d16(j);
+      d16(lm - 16);
+    } else if (lm >= 8) {
+      uint64_t x, y, x2, y2;
+      __builtin_memcpy(&x, a, 8); __builtin_memcpy(&y, b, 8);
+      __builtin_memcpy(&x2, a + lm - 8, 8); __builtin_memcpy(&y2, b + lm - 8, 8);
+      diff |= (x ^ y) | (x2 ^ y2);
+    } else if (lm >= 4) {
+      uint32_t x, y, x2, y2;
+      __builtin_memcpy(&x, a, 4); __builtin_memcpy(&y, b, 4);
+      __builtin_memcpy(&x2, a + lm - 4, 4); __builtin_memcpy(&y2, b + lm - 4, 4);
+      diff |= (uint64_t)((x ^ y) | (x2 ^ y2));
+    } else {
+      for (uint64_t j = 0; j < lm; ++j) diff |= (uint64_t)(a[j] ^ b[j]);
     }
-    for (; same && j < lm; ++j) same = a[j] == b[j];
   }
-  if (!same) *collision = 1;
+  if (diff) *collision = 1;
 }
 
 __global__ void __launch_bounds__(256)
 k_dict_assign(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot, const uint8_t* __restrict__ first,
-              const uint32_t* __restrict__ first_scan, uint64_t n_occ, uint32_t* __restrict__ slot_id,
+              const uint32_t* __restrict__ first_scan, uint64_t n_occ, DictSlot* __restrict__ ht,
               uint32_t* __restrict__ term_len, uint64_t* __restrict__ term_src) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_occ || !first[i]) return;
   const uint32_t id = first_scan[i];
-  slot_id[t_slot[i]] = id;
+  ht[t_slot[i]].val = id;  // the representative word has done its job: the slot now maps hash -> id
   term_len[id] = (uint32_t)(t_rep[i] & ((1ull << kRepLenBits) - 1));
   term_src[id] = t_rep[i] >> kRepLenBits;
 }
 
 // Encoded records (s, p, o as term ids) + per-term flags that follow from the record kinds.
 __global__ void __launch_bounds__(256)
-k_encode(const uint32_t* __restrict__ t_slot, const uint32_t* __restrict__ slot_id, const uint8_t* __restrict__ kind,
+k_encode(const uint32_t* __restrict__ t_slot, const DictSlot* __restrict__ ht, const uint8_t* __restrict__ kind,
          uint32_t n_rec, uint32_t* __restrict__ S, uint32_t* __restrict__ P, uint32_t* __restrict__ O,
          uint8_t* __restrict__ term_flags, uint8_t* __restrict__ is_pred) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rec) return;
-  const uint32_t s = slot_id[t_slot[3ull * r]], p = slot_id[t_slot[3ull * r + 1]], o = slot_id[t_slot[3ull * r + 2]];
+  const uint32_t s = (uint32_t)ht[t_slot[r]].val, p = (uint32_t)ht[t_slot[(uint64_t)n_rec + r]].val,
+                 o = (uint32_t)ht[t_slot[2ull * n_rec + r]].val;
   S[r] = s; P[r] = p; O[r] = o;
   is_pred[p] = 1;
   const uint8_t k = kind[r];
@@ -523,7 +599,7 @@ k_pool_copy(const uint8_t* __restrict__ text, const uint64_t* __restrict__ term_
 // Looks strings up: hash, probe, byte-compare against the pool.
 __global__ void __launch_bounds__(64)
 k_lookup(const uint8_t* __restrict__ q, const uint64_t* __restrict__ q_off, uint32_t nq, uint64_t seed,
-         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, uint64_t mask,
+         const DictSlot* __restrict__ ht, uint64_t mask,
          const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
@@ -532,10 +608,10 @@ k_lookup(const uint8_t* __restrict__ q, const uint64_t* __restrict__ q_off, uint
   uint64_t slot = h & mask;
   int64_t res = -1;
   for (;;) {
-    const uint64_t cur = keys[slot];
+    const uint64_t cur = ht[slot].key;
     if (cur == 0) break;
     if (cur == h) {
-      const uint32_t id = ids[slot];
+      const uint32_t id = (uint32_t)ht[slot].val;
       const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
       bool same = pl == e - b;
       for (uint64_t j = 0; same && j < pl; ++j) same = pool[pb + j] == q[b + j];
@@ -550,14 +626,14 @@ k_lookup(const uint8_t* __restrict__ q, const uint64_t* __restrict__ q_off, uint
 // Rebuilds the lookup table from the pool (dictionary loaded from disk).
 __global__ void __launch_bounds__(256)
 k_table_from_pool(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, uint64_t n_terms, uint64_t seed,
-                  uint64_t* __restrict__ keys, uint32_t* __restrict__ ids, uint64_t mask, uint32_t* __restrict__ collision) {
+                  DictSlot* __restrict__ ht, uint64_t mask, uint32_t* __restrict__ collision) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_terms) return;
   const uint64_t h = hash_range(pool, pool_off[t], pool_off[t + 1], seed);
   uint64_t slot = h & mask;
   for (;;) {
-    const uint64_t cur = atomicCAS((unsigned long long*)&keys[slot], 0ull, (unsigned long long)h);
-    if (cur == 0) { ids[slot] = (uint32_t)t; break; }
+    const uint64_t cur = atomicCAS((unsigned long long*)&ht[slot].key, 0ull, (unsigned long long)h);
+    if (cur == 0) { ht[slot].val = t; break; }
     if (cur == h) { *collision = 1; break; }  // two pool strings are distinct by construction
     slot = (slot + 1) & mask;
   }
@@ -796,8 +872,9 @@ struct StageTimer {
 
 }  // namespace
 
+// Stages 10 and 11 are the two big kernels inside "dictionary", timed on their own.
 const char* const kStageNames[12] = {"line_scan", "tokenise_hash", "dictionary", "string_pool", "vertex_masks", "sort_triples",
-                                     "place", "split_partitions", "node_index", "vp_index", "", ""};
+                                     "place", "split_partitions", "node_index", "vp_index", "dict_insert_kernel", "dict_verify_kernel"};
 
 void dict_build_table(dx_ctx* ctx) {
   Dictionary& d = ctx->dict;
@@ -806,14 +883,13 @@ void dict_build_table(dx_ctx* ctx) {
   while (cap < d.n_terms * 2) cap <<= 1;
   DevBuf<uint32_t> coll(ctx->pool, 1);
   for (int attempt = 0; attempt < 8; ++attempt) {
-    d.ht_keys = DevBuf<uint64_t>(ctx->pool, cap);
-    d.ht_ids = DevBuf<uint32_t>(ctx->pool, cap);
+    d.ht = DevBuf<DictSlot>(ctx->pool, cap);
     d.ht_mask = cap - 1;
-    DX_HIP(hipMemsetAsync(d.ht_keys.p, 0, cap * 8, s));
+    DX_HIP(hipMemsetAsync(d.ht.p, 0, cap * sizeof(DictSlot), s));
     DX_HIP(hipMemsetAsync(coll.p, 0, 4, s));
     if (d.n_terms)
       hipLaunchKernelGGL(k_table_from_pool, dim3(blocks(d.n_terms)), dim3(256), 0, s, d.pool.p, d.pool_off.p, d.n_terms, d.seed,
-                         d.ht_keys.p, d.ht_ids.p, d.ht_mask, coll.p);
+                         d.ht.p, d.ht_mask, coll.p);
     uint32_t c = 0;
     DX_HIP(hipMemcpyAsync(&c, coll.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
@@ -834,7 +910,7 @@ void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64
   DevBuf<int64_t> out(ctx->pool, n);
   DX_HIP(hipMemcpyAsync(q.p, bytes, nbytes, hipMemcpyHostToDevice, s));
   DX_HIP(hipMemcpyAsync(qo.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_lookup, dim3(blocks(n, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)n, d.seed, d.ht_keys.p, d.ht_ids.p,
+  hipLaunchKernelGGL(k_lookup, dim3(blocks(n, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)n, d.seed, d.ht.p,
                      d.ht_mask, d.pool.p, d.pool_off.p, out.p);
   DX_HIP(hipMemcpyAsync(ids_host, out.p, n * 8, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
@@ -886,11 +962,12 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<unsigned long long> err(pool, 1);
   DX_HIP(hipMemsetAsync(err.p, 0xFF, 8, s));
   DevBuf<uint32_t> tile_counts(pool, ntiles + 1);
+  DevBuf<uint16_t> chunk_mask(pool, (size_t)ntiles * (LS_TILE / 16) + 64);  // one 16-bit start mask per 16 bytes of text
   DevBuf<uint32_t> d_total(pool, 4);
   uint32_t n_rec = 0;
   if (n_bytes) {
     DX_HIP(hipMemsetAsync(tile_counts.p + ntiles, 0, 4, s));
-    hipLaunchKernelGGL(k_line_count, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, tile_counts.p, err.p);
+    hipLaunchKernelGGL(k_line_scan, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, err.p);
     exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, (size_t)ntiles + 1, d_total.p, s);
     DX_HIP(hipMemcpyAsync(&n_rec, d_total.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
@@ -903,53 +980,63 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint64_t> t_rep(pool, n_occ), t_hash(pool, n_occ);
   DevBuf<uint8_t> kind(pool, n_rec);
   DevBuf<uint32_t> t_slot(pool, n_occ);
+  // Table capacity: 1.5 slots per record to start with (LUBM-like data has ~0.55 distinct terms per
+  // record); a probe chain that runs too long reports overflow and the build restarts twice as large.
+  // 4 slots per record can never overflow (at most 3 distinct terms per record).
   uint64_t cap = 1024;
-  while (cap < 4ull * n_rec) cap <<= 1;
-  DevBuf<uint64_t> keys(pool, cap), rep(pool, cap);
-  DevBuf<uint32_t> slot_id(pool, cap);
+  while (cap < n_rec + n_rec / 2) cap <<= 1;
+  DevBuf<DictSlot> ht(pool, cap);
   DevBuf<uint8_t> first(pool, n_occ);
   DevBuf<uint32_t> first_scan(pool, n_occ);
-  DevBuf<uint32_t> coll(pool, 1);
+  DevBuf<uint32_t> coll(pool, 2);  // [0] true hash collision, [1] table overflow
   uint64_t seed = 0x243F6A8885A308D3ull;
   uint32_t n_terms = 0;
-  float ms_tok = 0, ms_dict = 0;
+  float ms_tok = 0, ms_insert = 0, ms_verify = 0;
+  bool tokenised = false;
   for (int attempt = 0;; ++attempt) {
-    // ---- 2. tokenise + hash
-    hipEvent_t e0, e1, e2;
-    DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2));
+    hipEvent_t e0, e1, e2, e3;
+    DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2)); DX_HIP(hipEventCreate(&e3));
+    // ---- 2. tokenise + hash (again only when the seed changed)
     DX_HIP(hipEventRecord(e0, s));
-    if (n_rec)
-      hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, tile_counts.p, seed,
-                         hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), t_rep.p,
-                         t_hash.p, kind.p, err.p);
+    if (n_rec && !tokenised)
+      hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed,
+                         hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec, t_rep.p,
+                         t_hash.p, kind.p, err.p, getenv("DX_TOK_EXP") ? atoi(getenv("DX_TOK_EXP")) : 0);
     DX_HIP(hipEventRecord(e1, s));
     // ---- 3. dictionary
-    DX_HIP(hipMemsetAsync(keys.p, 0, cap * 8, s));
-    DX_HIP(hipMemsetAsync(rep.p, 0xFF, cap * 8, s));
-    DX_HIP(hipMemsetAsync(coll.p, 0, 4, s));
-    if (n_occ) {
-      hipLaunchKernelGGL(k_dict_insert, dim3(blocks(n_occ)), dim3(256), 0, s, t_hash.p, t_rep.p, n_occ, keys.p, rep.p, cap - 1, t_slot.p);
-      hipLaunchKernelGGL(k_dict_verify, dim3(blocks(n_occ)), dim3(256), 0, s, text, t_rep.p, t_slot.p, n_occ, rep.p, first.p, coll.p);
-    }
-    exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
+    hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
+    DX_HIP(hipMemsetAsync(coll.p, 0, 8, s));
+    if (n_occ) hipLaunchKernelGGL(k_dict_insert, dim3(blocks(n_occ)), dim3(256), 0, s, t_hash.p, t_rep.p, n_occ, ht.p, cap - 1, t_slot.p, coll.p + 1);
     DX_HIP(hipEventRecord(e2, s));
+    if (n_occ) hipLaunchKernelGGL(k_dict_verify, dim3(blocks(n_occ)), dim3(256), 0, s, text, t_rep.p, t_slot.p, n_occ, ht.p, first.p, coll.p);
+    DX_HIP(hipEventRecord(e3, s));
+    exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
     unsigned long long h_err = ~0ull;
-    uint32_t h_coll = 0;
+    uint32_t h_coll[2] = {0, 0};
     DX_HIP(hipMemcpyAsync(&h_err, err.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(&h_coll, coll.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(h_coll, coll.p, 8, hipMemcpyDeviceToHost, s));
     DX_HIP(hipMemcpyAsync(&n_terms, d_total.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
-    float a = 0, b = 0;
-    DX_HIP(hipEventElapsedTime(&a, e0, e1)); DX_HIP(hipEventElapsedTime(&b, e1, e2));
-    ms_tok += a; ms_dict += b;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    float a = 0, b = 0, c = 0;
+    DX_HIP(hipEventElapsedTime(&a, e0, e1)); DX_HIP(hipEventElapsedTime(&b, e1, e2)); DX_HIP(hipEventElapsedTime(&c, e2, e3));
+    if (!tokenised) ms_tok = a;
+    ms_insert = b; ms_verify = c;
+    tokenised = true;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
                                         " (empty line, fewer than three fields, or a term of 16 MiB or more)");
-    if (!h_coll) break;
-    if (attempt >= 7) throw DxError(DX_E_RANGE, "dictionary: hash collisions persisted over 8 seeds");
+    if (h_coll[1]) {  // table too full for its probe bound
+      if (cap >= 4ull * n_rec && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 4 slots per record");
+      cap <<= 1;
+      ht = DevBuf<DictSlot>(pool, cap);
+      continue;
+    }
+    if (!h_coll[0]) break;
+    if (st.hash_retries >= 7) throw DxError(DX_E_RANGE, "dictionary: hash collisions persisted over 8 seeds");
     seed = mix64(seed + 0x9E3779B97F4A7C15ull);
     ++st.hash_retries;
+    tokenised = false;
   }
   st.n_terms = n_terms;
   Dictionary& d = ctx->dict;
@@ -964,17 +1051,16 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemsetAsync(is_pred.p, 0, n_terms ? n_terms : 1, s));
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
-    hipLaunchKernelGGL(k_dict_assign, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, slot_id.p,
+    hipLaunchKernelGGL(k_dict_assign, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, ht.p,
                        term_len.p, term_src.p);
-    hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_slot.p, slot_id.p, kind.p, n_rec, S.p, P.p, O.p,
+    hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_slot.p, ht.p, kind.p, n_rec, S.p, P.p, O.p,
                        ps.term_flags.p, is_pred.p);
   }
   // the build-time table doubles as the lookup table
-  d.ht_keys = std::move(keys);
-  d.ht_ids = std::move(slot_id);
+  d.ht = std::move(ht);
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
-  t_hash.reset(); t_slot.reset(); first.reset(); first_scan.reset(); rep.reset();
+  t_hash.reset(); t_slot.reset(); first.reset(); first_scan.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
@@ -1204,7 +1290,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   float total = 0;
   DX_HIP(hipEventElapsedTime(&total, tm.ev.front(), tm.ev.back()));
   st.ms_total = total;
-  (void)ms_dict;
+  st.ms_stage[10] = ms_insert;
+  st.ms_stage[11] = ms_verify;
   ps.valid = true;
 }
 

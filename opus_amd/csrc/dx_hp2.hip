@@ -63,7 +63,7 @@ __device__ __forceinline__ uint64_t hash_key2(int64_t a, int64_t b) { return mix
 
 // Constants -> term ids, on the device, so the host never waits for them.
 __global__ void __launch_bounds__(64)
-k_resolve_consts(ConstArgs ca, uint64_t seed, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, uint64_t mask,
+k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask,
                  const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
   const int i = threadIdx.x;
   if (i >= ca.n) return;
@@ -73,10 +73,10 @@ k_resolve_consts(ConstArgs ca, uint64_t seed, const uint64_t* __restrict__ keys,
   uint64_t slot = h & mask;
   int64_t res = -1;
   for (;;) {
-    const uint64_t cur = keys[slot];
+    const uint64_t cur = ht[slot].key;
     if (cur == 0) break;
     if (cur == h) {
-      const uint32_t id = ids[slot];
+      const uint32_t id = (uint32_t)ht[slot].val;
       const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
       bool same = pl == e - b;
       for (uint64_t j = 0; same && j < pl; ++j) same = pool[pb + j] == (uint8_t)ca.bytes[b + j];
@@ -440,7 +440,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       DX_HIP(hipEventRecord(ev0, s));
       DX_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * (MAXSTEPS + 2), s));
       if (ca.n)
-        hipLaunchKernelGGL(k_resolve_consts, dim3(1), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht_keys.p, ctx->dict.ht_ids.p,
+        hipLaunchKernelGGL(k_resolve_consts, dim3(1), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p,
                            ctx->dict.ht_mask, ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
       RelDev I{};
       std::vector<int> I_cls;

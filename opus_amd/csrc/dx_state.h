@@ -7,6 +7,14 @@ namespace dx {
 constexpr uint32_t kNil = 0xFFFFFFFFu;
 constexpr int kRepLenBits = 24;  // a term is at most 16 MiB; its first byte sits below 1 TiB
 
+// One slot of the open-addressing term table: 16 bytes, so a probe touches one memory sector. While the
+// table is being built `val` holds the smallest (offset << 24 | length) word among the occurrences
+// of the slot's hash; afterwards it holds the term id.
+struct DictSlot {
+  uint64_t key;
+  uint64_t val;
+};
+
 // Term dictionary resident in HBM. id -> bytes through pool/pool_off; bytes -> id through an
 // open-addressing table keyed by the 64-bit term hash (slot -> id), confirmed by byte compare.
 struct Dictionary {
@@ -14,8 +22,7 @@ struct Dictionary {
   uint64_t seed = 0;
   DevBuf<uint8_t> pool;        // concatenated term bytes, id order
   DevBuf<uint64_t> pool_off;   // n_terms + 1
-  DevBuf<uint64_t> ht_keys;    // hash or 0
-  DevBuf<uint32_t> ht_ids;     // id of the slot's term
+  DevBuf<DictSlot> ht;         // key = term hash (0 = empty), val = term id
   uint64_t ht_mask = 0;
   bool valid() const { return pool_off.p != nullptr; }
 };
