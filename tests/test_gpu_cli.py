@@ -1,0 +1,82 @@
+"""The two CLIs end to end: dx-dap writes the reference's layout, dx-query answers from it (a separate
+process with nothing resident), results file in the reference's format."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "opus_amd", "_lib")
+
+
+def test_dap_then_query_round_trip(lubm1, tmp_path):
+    from opus_amd import lubm
+    from opus_amd.host import translator as T
+    from oracle import dap_oracle, query_oracle
+    ref = lubm1["oracle"]
+    cwd = tmp_path
+    (cwd / "LUBM_local").mkdir()
+    (cwd / "LUBM_local" / "class_index.txt_4_bal").write_text(lubm1["class_index"])
+    (cwd / "instances.nt").write_bytes(bytes(lubm1["bytes"]))
+    base = str(cwd / "store")
+    env = dict(os.environ)
+
+    # wrong argument count: message and exit code of System.exit(-1)
+    p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM"], cwd=cwd, capture_output=True, text=True)
+    assert p.returncode == 255 and "-->Missing Arguments" in p.stdout
+
+    p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM", "4", base, str(cwd / "instances.nt"), "unused-schema-path"],
+                       cwd=cwd, capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DAP - partitioning time:" in p.stdout
+
+    clusters = os.path.join(base, "LUBM_data", "cluster", "clusters_4_bal")
+    # VP directory names = the oracle's (partition, _3=<sanitised predicate>) keys
+    got_dirs = {(d, s) for d in os.listdir(clusters) if os.path.isdir(os.path.join(clusters, d))
+                for s in os.listdir(os.path.join(clusters, d)) if s.startswith("_3=")}
+    assert got_dirs == set(ref["vp"])
+    assert os.path.isdir(os.path.join(base, "LUBM_data", "node_index_4"))
+    for q in range(4):
+        assert os.path.isdir(os.path.join(base, "LUBM_data", "classSubPart_index_4__%05d" % q))
+    stats = set((cwd / "LUBM_local" / "statistics.txt_4").read_text().split("\n")) - {""}
+    assert stats == ref["statistics"]
+    pstat = T.load_partition_stats((cwd / "LUBM_local" / "partition_stat.txt_4_bal").read_text())
+    assert pstat == ref["partition_stat"]
+
+    # second run: output exists, stage is skipped (DAP.scala:86)
+    p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM", "4", base, str(cwd / "instances.nt"), "x"], cwd=cwd, capture_output=True, text=True)
+    assert p.returncode == 0 and "nothing to do" in p.stdout
+
+    # translated queries written the way QueryTranslator.main does
+    ni = {}
+    for u, c in ref["node_index"]:
+        ni.setdefault(u, []).append(c)
+    ci = T.load_class_index(lubm1["class_index"])
+    qdir = cwd / "queries" / "translated_queries_4_bal"
+    qdir.mkdir(parents=True)
+    want = {}
+    for name, text in lubm.queries(0).items():
+        if name == "Q2.txt":
+            continue  # SQLite needs seconds for this 6-way join; covered by test_gpu_queries
+        tr = T.translate_query(name, text, lambda u: ni.get(u, []), ci, pstat)
+        (qdir / name).write_text(tr)
+        r = query_oracle.run_query(ref["vp"], tr)
+        want[name] = (r["count"], r["load_data"], r["tp"])
+
+    p = subprocess.run([os.path.join(BIN, "dx-query"), "LUBM", "4", base, str(qdir)], cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    seen = {}
+    for tp in {w[2] for w in want.values()}:
+        lines = (cwd / "results" / "LUBM" / "4_bal" / ("results_%d_bal.txt" % tp)).read_text().split("\n")
+        rec = {}
+        for line in lines:
+            if ": " in line:
+                k, v = line.split(": ", 1)
+                rec[k] = v
+                if k == "partitions":
+                    seen[rec["Query"]] = (int(rec["Result_count"]), int(rec["Load_data"]), tp)
+                    assert set(rec) == {"Query", "Time", "Time_us", "Time_load", "Load_data", "Result_count", "partitions"}
+                    rec = {}
+    assert seen == want
