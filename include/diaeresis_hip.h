@@ -145,6 +145,9 @@ int dx_result_fetch_ids(dx_result* r, int64_t* ids, int sorted);
 /* Ids <= -2 in a result are constants projected by the statement itself (`'<...>' AS P`,
  * QueryTranslator.scala:485-526), which are not dictionary terms; this returns their text, or NULL. */
 const char* dx_result_virtual_term(dx_result* r, int64_t id);
+/* The executed plan as text, one line per step: tables, filters, rows after the step (what the reference
+ * gets from result.explain, QueryProcessor.scala:178). */
+const char* dx_result_plan(dx_result* r);
 /* Device time of the statement in milliseconds (hipEvents around the launches). */
 double dx_result_device_ms(dx_result* r);
 void dx_result_free(dx_result* r);

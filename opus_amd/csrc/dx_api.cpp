@@ -177,6 +177,7 @@ void dx_free(dx_ctx* ctx) {
   ctx->dict = Dictionary();
   ctx->qws.reset();
   ctx->pool.trim();
+  if (ctx->q_ev0) { (void)hipEventDestroy(ctx->q_ev0); (void)hipEventDestroy(ctx->q_ev1); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -533,6 +534,7 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
     const std::string offs = read_file(dd + "/offsets.bin"), terms = read_file(dd + "/terms.bin");
     if (offs.size() < 8 || offs.size() % 8) throw DxError(DX_E_IO, "corrupt dictionary offsets");
     ctx->catalog.clear();
+    ctx->table_stats.clear();
     ctx->part = PartitionState();
     Dictionary nd;
     nd.n_terms = offs.size() / 8 - 1;
@@ -635,6 +637,14 @@ int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
       it = ctx->catalog.emplace(view, std::move(t)).first;
       it->second.s = it->second.own_s.p ? it->second.own_s.p : it->second.s;
       it->second.o = it->second.own_o.p ? it->second.own_o.p : it->second.o;
+      auto st = ctx->table_stats.find(key);  // statistics survive unloadTables: the data did not change
+      if (st == ctx->table_stats.end()) {
+        table_statistics(ctx, it->second);
+        ctx->table_stats[key] = {it->second.distinct_s, it->second.distinct_o};
+      } else {
+        it->second.distinct_s = st->second.first;
+        it->second.distinct_o = st->second.second;
+      }
     }
     if (rows) *rows = it->second.rows;
   });
@@ -706,6 +716,8 @@ const char* dx_result_virtual_term(dx_result* r, int64_t id) {
   if (!r || id > -2 || (size_t)(-id - 2) >= r->virtual_terms.size()) return nullptr;
   return r->virtual_terms[(size_t)(-id - 2)].c_str();
 }
+
+const char* dx_result_plan(dx_result* r) { return r ? r->plan.c_str() : ""; }
 
 void dx_result_free(dx_result* r) { delete r; }
 

@@ -511,8 +511,13 @@ k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ 
 __global__ void __launch_bounds__(256)
 k_dict_verify(const uint8_t* __restrict__ text, const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot,
               uint64_t n_occ, const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_occ) return;
+  // Threads walk the occurrences record by record (s, p, o of record 0, then of record 1, ...) although
+  // the arrays are field-major: that way a wave re-reads one contiguous stretch of the text once, instead
+  // of every field pass pulling every cache line of the text through HBM again.
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_occ) return;
+  const uint64_t n_rec = n_occ / 3;
+  const uint64_t i = (t % 3) * n_rec + t / 3;
   const uint64_t mine = t_rep[i], r = ht[t_slot[i]].val;
   if (mine == r) { first[i] = 1; return; }
   first[i] = 0;
@@ -583,17 +588,29 @@ k_encode(const uint32_t* __restrict__ t_slot, const DictSlot* __restrict__ ht, c
   else { set_flag(s, kFlagVertex); if (k == 2) set_flag(o, kFlagLiteral); }
 }
 
-// Copies term bytes from the input text into the id-ordered pool.
+// Copies term bytes from the input text into the id-ordered pool: one thread per term, 16 bytes at a
+// time (unaligned wide loads and stores), the last chunk overlapping the one before instead of a byte tail.
+// Neighbouring threads write neighbouring pool ranges.
 __global__ void __launch_bounds__(256)
 k_pool_copy(const uint8_t* __restrict__ text, const uint64_t* __restrict__ term_src, const uint64_t* __restrict__ pool_off,
             uint64_t n_terms, uint8_t* __restrict__ pool) {
-  // one wave per term: 64 lanes stride over the bytes
-  const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_terms) return;
-  const int lane = threadIdx.x & 63;
   const uint64_t b = pool_off[t], len = pool_off[t + 1] - b;
   const uint8_t* src = text + term_src[t];
-  for (uint64_t j = lane; j < len; j += 64) pool[b + j] = src[j];
+  uint8_t* dst = pool + b;
+  if (len >= 16) {
+    for (uint64_t j = 0; j + 16 < len; j += 16) {
+      uint4 v;
+      __builtin_memcpy(&v, src + j, 16);
+      __builtin_memcpy(dst + j, &v, 16);
+    }
+    uint4 v;
+    __builtin_memcpy(&v, src + len - 16, 16);
+    __builtin_memcpy(dst + len - 16, &v, 16);
+  } else {
+    for (uint64_t j = 0; j < len; ++j) dst[j] = src[j];
+  }
 }
 
 // Looks strings up: hash, probe, byte-compare against the pool.
@@ -653,6 +670,22 @@ k_vertex_masks(const uint32_t* __restrict__ S, const uint32_t* __restrict__ O, c
   if (r >= n_rec || kind[r] != 1) return;
   const uint64_t m = Pm[O[r]];
   if (m && (M[S[r]] & m) != m) atomicOr((unsigned long long*)&M[S[r]], (unsigned long long)m);
+}
+
+// pred_terms[pred_index[t]] = t for every term used as a predicate; also counts vertices
+__global__ void __launch_bounds__(256)
+k_list_preds(const uint8_t* __restrict__ is_pred, const uint32_t* __restrict__ pred_index, const uint8_t* __restrict__ flags,
+             uint32_t n_terms, uint32_t* __restrict__ pred_terms, unsigned long long* __restrict__ n_vertices) {
+  __shared__ uint32_t lds[8];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = 0;
+  if (t < n_terms) {
+    if (is_pred[t]) pred_terms[pred_index[t]] = t;
+    v = (flags[t] & kFlagVertex) ? 1u : 0u;
+  }
+  uint32_t total;
+  (void)block_excl_scan_256<uint32_t>(v, lds, total);
+  if (threadIdx.x == 0 && total) atomicAdd(n_vertices, (unsigned long long)total);
 }
 
 // ---- 5. sort keys, placement masks -----------------------------------------------------------------------
@@ -942,6 +975,46 @@ static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514 
   return out;
 }
 
+// Distinct values of the two columns of a table (load time, untimed by the reference as well: it is part
+// of caching the table, QueryProcessor.scala:222-232). Subjects are counted on the stored order when the
+// table is one sorted slice, otherwise both columns go through a radix sort of a copy.
+__global__ void __launch_bounds__(256)
+k_count_changes(const uint64_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ out) {
+  __shared__ uint32_t lds[8];
+  uint32_t c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    c += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+  uint32_t total;
+  (void)block_excl_scan_256<uint32_t>(c, lds, total);
+  if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
+}
+
+void table_statistics(dx_ctx* ctx, CatalogTable& t) {
+  hipStream_t s = ctx->stream;
+  if (t.rows == 0) { t.distinct_s = t.distinct_o = 0; return; }
+  DevBuf<unsigned long long> cnt(ctx->pool, 2);
+  DX_HIP(hipMemsetAsync(cnt.p, 0, 16, s));
+  const int bits = ctx->dict.valid() ? bits_for(ctx->dict.n_terms ? ctx->dict.n_terms : 1) : 64;
+  const unsigned g = (unsigned)std::min<uint64_t>(2048, (t.rows + 255) / 256);
+  DevBuf<uint64_t> tmp(ctx->pool, t.rows);
+  const bool sorted_s = t.slices.size() <= 1;
+  for (int col = 0; col < 2; ++col) {
+    const int64_t* src = col == 0 ? t.s : t.o;
+    const uint64_t* keys = (const uint64_t*)src;
+    if (!(col == 0 && sorted_s)) {
+      DX_HIP(hipMemcpyAsync(tmp.p, src, t.rows * 8, hipMemcpyDeviceToDevice, s));
+      radix_sort_u64(ctx->pool, tmp.p, nullptr, t.rows, bits, s);
+      keys = tmp.p;
+    }
+    hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, keys, t.rows, cnt.p + col);
+  }
+  unsigned long long h[2] = {0, 0};
+  DX_HIP(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  t.distinct_s = h[0];
+  t.distinct_o = h[1];
+}
+
 void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
                    int nparts) {
   hipStream_t s = ctx->stream;
@@ -949,6 +1022,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   if (nparts < 1 || nparts > DX_MAX_PARTITIONS) throw DxError(DX_E_INVAL, "n_partitions must be in [1, 64]");
   if (n_bytes >= (1ull << (64 - kRepLenBits))) throw DxError(DX_E_RANGE, "input larger than 1 TiB");
   ctx->catalog.clear();
+  ctx->table_stats.clear();
   ctx->part = PartitionState();
   ctx->dict = Dictionary();
   PartitionState& ps = ctx->part;
@@ -1070,7 +1144,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemcpyAsync(&pool_bytes, d_total64.p, 8, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
   d.pool = DevBuf<uint8_t>(pool, pool_bytes + 16);
-  if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks((uint64_t)n_terms * 64)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
+  if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks((uint64_t)n_terms)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
                                   (uint64_t)n_terms, d.pool.p);
   tm.mark();
   t_rep.reset(); term_src.reset(); term_len.reset();
@@ -1110,13 +1184,21 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipStreamSynchronize(s));
   st.n_predicates = np;
   {
-    std::vector<uint8_t> hp(n_terms);
-    if (n_terms) DX_HIP(hipMemcpy(hp.data(), is_pred.p, n_terms, hipMemcpyDeviceToHost));
-    for (uint32_t t = 0; t < n_terms; ++t)
-      if (hp[t]) ps.pred_terms.push_back(t);
+    DevBuf<uint32_t> d_preds(pool, np ? np : 1);
+    DevBuf<unsigned long long> d_nv(pool, 1);
+    DX_HIP(hipMemsetAsync(d_nv.p, 0, 8, s));
+    if (n_terms)
+      hipLaunchKernelGGL(k_list_preds, dim3(blocks(n_terms)), dim3(256), 0, s, is_pred.p, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
+    std::vector<uint32_t> hp(np);
+    unsigned long long nv = 0;
+    if (np) DX_HIP(hipMemcpyAsync(hp.data(), d_preds.p, (size_t)np * 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(&nv, d_nv.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    ps.pred_terms.assign(hp.begin(), hp.end());
+    st.n_vertices = nv;
   }
   const int bits_term = bits_for(n_terms ? n_terms : 1), bits_pred = bits_for(np ? np : 1);
-  if (bits_pred + 2 * bits_term > 64 || 6 + bits_term + 1 + bits_pred > 64)
+  if (bits_pred + 2 * bits_term > 64 || bits_for(nparts) + bits_term + 1 + bits_pred > 64)
     throw DxError(DX_E_RANGE, "dictionary too large for 64-bit packed sort keys on one GPU");
   ps.bits_term = bits_term;
   for (uint32_t i = 0; i < np; ++i)
@@ -1207,7 +1289,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     hipLaunchKernelGGL(k_vpi_emit<true>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
                        ps.type_pidx, ps.term_flags.p, bits_term, bits_pred, nullptr, pos.p, ent.p);
     cnt.reset(); pos.reset();
-    radix_sort_u64(pool, ent.p, nullptr, n_ent, 6 + bits_term + 1 + bits_pred, s);
+    radix_sort_u64(pool, ent.p, nullptr, n_ent, bits_for(nparts) + bits_term + 1 + bits_pred, s);
     DevBuf<uint8_t> fl(pool, n_ent);
     DevBuf<uint32_t> fp(pool, n_ent);
     if (n_ent) hipLaunchKernelGGL(k_flag_distinct, dim3(blocks(n_ent)), dim3(256), 0, s, ent.p, n_ent, fl.p);
@@ -1236,15 +1318,17 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     uint64_t total = 0;
     if (np) {
       std::vector<uint64_t> po(np * 2);
-      // predicate strings: fetch offsets one by one (np is small next to the data)
+      for (uint32_t i = 0; i < np; ++i)  // queued copies, one wait
+        DX_HIP(hipMemcpyAsync(&po[2 * i], d.pool_off.p + ids[i], 16, hipMemcpyDeviceToHost, s));
+      DX_HIP(hipStreamSynchronize(s));
+      for (uint32_t i = 0; i < np; ++i) ps.pred_strings.emplace_back(po[2 * i + 1] - po[2 * i], '\0');
       for (uint32_t i = 0; i < np; ++i)
-        DX_HIP(hipMemcpy(&po[2 * i], d.pool_off.p + ids[i], 16, hipMemcpyDeviceToHost));
+        if (!ps.pred_strings[i].empty())
+          DX_HIP(hipMemcpyAsync(&ps.pred_strings[i][0], d.pool.p + po[2 * i], ps.pred_strings[i].size(), hipMemcpyDeviceToHost, s));
+      DX_HIP(hipStreamSynchronize(s));
       for (uint32_t i = 0; i < np; ++i) {
-        std::string str(po[2 * i + 1] - po[2 * i], '\0');
-        if (!str.empty()) DX_HIP(hipMemcpy(&str[0], d.pool.p + po[2 * i], str.size(), hipMemcpyDeviceToHost));
-        ps.pred_strings.push_back(str);
-        ps.pred_storage.push_back(uri_to_storage(str));
-        total += str.size();
+        ps.pred_storage.push_back(uri_to_storage(ps.pred_strings[i]));
+        total += ps.pred_strings[i].size();
       }
     }
     (void)total; (void)offs;
@@ -1266,15 +1350,6 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     });
     st.n_tables = (uint32_t)ps.tables.size();
   }
-  // vertices = terms flagged as vertex
-  {
-    std::vector<uint8_t> hf(n_terms);
-    if (n_terms) DX_HIP(hipMemcpy(hf.data(), ps.term_flags.p, n_terms, hipMemcpyDeviceToHost));
-    uint64_t nv = 0;
-    for (auto f : hf) nv += (f & kFlagVertex) ? 1 : 0;
-    st.n_vertices = nv;
-  }
-
   // ---- stage times
   std::vector<float> gaps;
   for (size_t i = 1; i < tm.ev.size(); ++i) {

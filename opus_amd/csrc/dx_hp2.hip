@@ -16,6 +16,8 @@
 //     statement is run again with that capacity.
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <sstream>
 
 #include "dx_device.h"
 #include "dx_sql.h"
@@ -61,31 +63,35 @@ struct ConstArgs {
 __device__ __forceinline__ uint64_t hash_key(int64_t a) { return mix64((uint64_t)a * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull); }
 __device__ __forceinline__ uint64_t hash_key2(int64_t a, int64_t b) { return mix64(hash_key(a) ^ ((uint64_t)b * 0xC2B2AE3D27D4EB4Full)); }
 
-// Constants -> term ids, on the device, so the host never waits for them.
+// Constants -> term ids, on the device, so the host never waits for them. One wave per constant:
+// lane 0 walks the probe chain, then all lanes compare the bytes eight at a time.
 __global__ void __launch_bounds__(64)
 k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask,
                  const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
-  const int i = threadIdx.x;
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= ca.n) return;
-  if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) { out[i] = ca.preset[i]; return; }
-  const uint32_t b = ca.off[i], e = ca.off[i + 1];
+  if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) { if (lane == 0) out[i] = ca.preset[i]; return; }
+  const uint32_t b = ca.off[i], e = ca.off[i + 1], len = e - b;
   const uint64_t h = ca.hash[i];
-  uint64_t slot = h & mask;
-  int64_t res = -1;
-  for (;;) {
-    const uint64_t cur = ht[slot].key;
-    if (cur == 0) break;
-    if (cur == h) {
-      const uint32_t id = (uint32_t)ht[slot].val;
-      const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
-      bool same = pl == e - b;
-      for (uint64_t j = 0; same && j < pl; ++j) same = pool[pb + j] == (uint8_t)ca.bytes[b + j];
-      if (same) res = id;
-      break;
+  long long id = -1;
+  if (lane == 0) {
+    uint64_t slot = h & mask;
+    for (;;) {
+      const uint64_t cur = ht[slot].key;
+      if (cur == 0) break;
+      if (cur == h) { id = (long long)(uint32_t)ht[slot].val; break; }  // one slot per hash
+      slot = (slot + 1) & mask;
     }
-    slot = (slot + 1) & mask;
   }
-  out[i] = res;
+  id = __shfl(id, 0, 64);
+  if (id < 0) { if (lane == 0) out[i] = -1; return; }
+  const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
+  bool same = pl == len;
+  if (same) {
+    for (uint32_t j = lane; j < len; j += 64) same &= pool[pb + j] == (uint8_t)ca.bytes[b + j];
+  }
+  same = __all(same);
+  if (lane == 0) out[i] = same ? id : -1;
 }
 
 __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, uint32_t i, int64_t v[3]) {
@@ -248,7 +254,8 @@ struct PlanRel {
   };
   std::vector<Arm> arms;
   uint64_t rows_upper = 0;
-  double est = 0;
+  double est = 0;                // estimated rows after the constant filters
+  double dist[3] = {1, 1, 1};    // estimated distinct values per projected column
 };
 
 struct Plan {
@@ -258,6 +265,7 @@ struct Plan {
   std::vector<int> select_cls;
   std::vector<std::string> select_names;
   std::vector<std::string> virtual_terms;
+  std::vector<double> est_rows;  // estimated rows after each step of the chosen order
   int n_classes = 0;
 };
 
@@ -349,27 +357,79 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
       }
       r.arms.push_back(a);
       r.rows_upper += it->second.rows;
-      const bool type_table = arm.table.size() > 6 && arm.table.rfind("_type_") == arm.table.size() - 6;
-      sel = arm.has_s ? 1e-4 : arm.has_o ? (type_table ? 0.2 : 1e-4) : 1.0;
+      // uniform-frequency estimate from the table's row and distinct counts (gathered when it was loaded)
+      const CatalogTable& t = it->second;
+      const double n = (double)t.rows, ds = (double)std::max<uint64_t>(t.distinct_s, 1), dob = (double)std::max<uint64_t>(t.distinct_o, 1);
+      double rows = n;
+      if (arm.has_s) rows /= ds;
+      if (arm.has_o) rows /= dob;
+      rows = std::max(rows, n > 0 ? 1.0 : 0.0);
+      r.est += rows;
+      for (int c = 0; c < r.ncols; ++c) {
+        const double d = a.src[c] == 0 ? (arm.has_s ? 1.0 : std::min(ds, rows)) : a.src[c] == 1 ? (arm.has_o ? 1.0 : std::min(dob, rows)) : 1.0;
+        r.dist[c] = (&arm == &sub.arms[0]) ? d : r.dist[c] + d;
+      }
+      (void)sel;
     }
-    r.est = (double)r.rows_upper * sel;
     rels.push_back(std::move(r));
   }
   if ((int)plan.const_str.size() > kMaxConsts) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 32 constants");
-  // greedy left-deep order: cheapest first, then always the cheapest relation sharing a bound variable
-  std::vector<bool> used(rels.size(), false), bound(plan.n_classes, false);
-  for (size_t k = 0; k < rels.size(); ++k) {
-    int best = -1;
-    bool best_conn = false;
-    for (size_t i = 0; i < rels.size(); ++i) {
-      if (used[i]) continue;
-      bool conn = false;
-      for (int c = 0; c < rels[i].ncols; ++c) conn |= bound[rels[i].cls[c]];
-      if (best < 0 || (conn && !best_conn) || (conn == best_conn && rels[i].est < rels[best].est)) { best = (int)i; best_conn = conn; }
-    }
-    used[best] = true;
-    for (int c = 0; c < rels[best].ncols; ++c) bound[rels[best].cls[c]] = true;
-    plan.rels.push_back(rels[best]);
+  // Join order: exhaustive search over left-deep orders (a BGP has a handful of sub-selects) for the one with
+  // the smallest sum of estimated intermediate sizes; an order may only take a relation that shares a
+  // variable with what is bound, unless none is left that does. Size of I |x| R on shared variables K:
+  // |I| * |R| / prod over K of max(distinct_I(v), distinct_R(v)).
+  {
+    const int n = (int)rels.size();
+    std::vector<int> best_order, cur;
+    std::vector<double> best_rows, cur_rows;
+    double best_cost = 1e300;
+    std::vector<bool> used(n, false);
+    long budget = 200000;  // nodes of the search tree; beyond it the best order found so far is used
+    struct State { double rows; std::vector<double> d; };
+    std::function<void(const State&, double)> dfs = [&](const State& st, double cost) {
+      if (cost >= best_cost || --budget < 0) return;
+      if ((int)cur.size() == n) { best_cost = cost; best_order = cur; best_rows = cur_rows; return; }
+      bool any_conn = false;
+      for (int i = 0; i < n && !cur.empty(); ++i) {
+        if (used[i]) continue;
+        for (int c = 0; c < rels[i].ncols; ++c) any_conn |= st.d[rels[i].cls[c]] > 0;
+      }
+      for (int i = 0; i < n; ++i) {
+        if (used[i]) continue;
+        const PlanRel& r = rels[i];
+        bool conn = false;
+        for (int c = 0; c < r.ncols; ++c) conn |= st.d[r.cls[c]] > 0;
+        if (!cur.empty() && any_conn && !conn) continue;
+        State nx = st;
+        if (cur.empty()) {
+          nx.rows = r.est;
+        } else {
+          double rows = st.rows * r.est;
+          for (int c = 0; c < r.ncols; ++c)
+            if (st.d[r.cls[c]] > 0) rows /= std::max(1.0, std::max(st.d[r.cls[c]], r.dist[c]));
+          nx.rows = rows;
+        }
+        for (int c = 0; c < r.ncols; ++c) {
+          const double old = st.d[r.cls[c]];
+          nx.d[r.cls[c]] = old > 0 ? std::min(old, r.dist[c]) : r.dist[c];
+        }
+        for (auto& x : nx.d)
+          if (x > 0) x = std::max(1.0, std::min(x, std::max(nx.rows, 1.0)));
+        used[i] = true;
+        cur.push_back(i);
+        cur_rows.push_back(nx.rows);
+        // the last step of a count query is not materialised, and every step streams its table once
+        dfs(nx, cost + ((int)cur.size() == n ? 0.0 : nx.rows) + 0.05 * (double)r.rows_upper);
+        cur.pop_back();
+        cur_rows.pop_back();
+        used[i] = false;
+      }
+    };
+    State st0{0.0, std::vector<double>(plan.n_classes, 0.0)};
+    dfs(st0, 0.0);
+    for (int i : best_order) plan.rels.push_back(rels[i]);
+    plan.est_rows = best_rows;
+    if ((int)plan.rels.size() != n) throw DxError(DX_E_INVAL, "planner found no join order");
   }
   if ((int)plan.rels.size() > MAXSTEPS) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 30 sub-selects");
   return plan;
@@ -424,9 +484,8 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
   if (!hb) DX_HIP(hipHostMalloc((void**)&hb, sizeof(QueryHostBlock), hipHostMallocDefault));
 
   std::vector<uint64_t> caps(nsteps, 0);
-  hipEvent_t ev0, ev1;
-  DX_HIP(hipEventCreate(&ev0));
-  DX_HIP(hipEventCreate(&ev1));
+  if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }
+  hipEvent_t ev0 = ctx->q_ev0, ev1 = ctx->q_ev1;
   auto* res = new dx_result();
   res->ctx = ctx;
   res->names = plan.select_names;
@@ -440,7 +499,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       DX_HIP(hipEventRecord(ev0, s));
       DX_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * (MAXSTEPS + 2), s));
       if (ca.n)
-        hipLaunchKernelGGL(k_resolve_consts, dim3(1), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p,
+        hipLaunchKernelGGL(k_resolve_consts, dim3(ca.n), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p,
                            ctx->dict.ht_mask, ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
       RelDev I{};
       std::vector<int> I_cls;
@@ -518,7 +577,10 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
         out.ncols = (int)I_cls.size() + pa.nnew;
         out.count = cnt;
         if (!count_only) {
-          const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : std::max<uint64_t>(I.cap, r.rows_upper), 1);
+          // optimistic capacity: what flows in, or twice the estimate if that is more; a miss costs one re-run
+          const uint64_t guess = std::max<uint64_t>(std::max<uint64_t>(I.cap, r.rows_upper),
+                                                    (uint64_t)std::min(2.0 * plan.est_rows[k], 4.0e8));
+          const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : guess, 1);
           if (cap >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
           for (int c = 0; c < out.ncols; ++c) { step_cols[k].emplace_back(pool, cap); out.col[c] = step_cols[k].back().p; }
           out.cap = (uint32_t)cap;
@@ -537,6 +599,15 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       DX_HIP(hipEventRecord(ev1, s));
       DX_HIP(hipStreamSynchronize(s));
       DX_HIP(hipGetLastError());
+      std::ostringstream explain;
+      for (int k = 0; k < nsteps; ++k) {
+        const PlanRel& r = plan.rels[k];
+        explain << (k ? "join " : "scan ");
+        for (size_t a = 0; a < r.arms.size(); ++a)
+          explain << (a ? " UNION " : "") << r.arms[a].t->view << "[" << r.arms[a].t->rows << " rows"
+                  << (r.arms[a].fs >= 0 ? ", s filter" : "") << (r.arms[a].fo >= 0 ? ", o filter" : "") << "]";
+        explain << " -> " << hb->counters[k] << " rows\n";
+      }
       bool overflow = false;
       const bool final_counts_only = mode == DX_QUERY_COUNT;
       for (int k = 0; k < nsteps; ++k) {
@@ -566,14 +637,11 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
         }
         DX_HIP(hipStreamSynchronize(s));
       }
-      (void)hipEventDestroy(ev0);
-      (void)hipEventDestroy(ev1);
+      res->plan = explain.str();
       return res;
     }
     throw DxError(DX_E_RANGE, "query did not converge on buffer sizes");
   } catch (...) {
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     delete res;
     throw;
   }

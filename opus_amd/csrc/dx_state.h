@@ -70,6 +70,7 @@ struct CatalogTable {
   std::string key;      // "00001-_3=<pred>"
   std::string view;     // "table00001__3_E_<pred>"
   uint64_t rows = 0;
+  uint64_t distinct_s = 0, distinct_o = 0;  // gathered at load time, feed the join-order estimates
   // a view is the concatenation of one or more row slices (several predicates can sanitise to one name)
   struct Slice { const int64_t* s; const int64_t* o; uint64_t rows; };
   std::vector<Slice> slices;
@@ -89,11 +90,13 @@ struct dx_ctx {
   dx::Dictionary dict;
   dx::PartitionState part;
   std::map<std::string, dx::CatalogTable> catalog;   // by view name
+  std::map<std::string, std::pair<uint64_t, uint64_t>> table_stats;  // by table key: distinct s, distinct o
   // dataset opened from disk
   std::string ds_base, ds_name;
   int ds_partitions = 0;
   // query workspace
   dx::DevBuf<uint8_t> qws;
+  hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
 };
 
 struct dx_result {
@@ -104,6 +107,7 @@ struct dx_result {
   std::vector<std::string> names;
   std::vector<dx::DevBuf<int64_t>> cols;   // one per selected column (bindings mode)
   std::vector<std::string> virtual_terms;  // projected constants: id -(2 + index)
+  std::string plan;                        // join order with the row count after every step
 };
 
 namespace dx {
@@ -112,6 +116,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const s
                    int n_partitions);
 void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids_host);
 void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
+void table_statistics(dx_ctx* ctx, CatalogTable& t);  // distinct subjects / objects
 // dx_hp2.hip
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
 extern const char* const kStageNames[12];

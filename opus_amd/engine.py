@@ -29,7 +29,7 @@ EXPORTS = [
     "dx_node_index_fetch", "dx_vp_index_rows", "dx_vp_index_fetch", "dx_instance_graph_sizes",
     "dx_instance_graph_fetch", "dx_part_write_layout", "dx_open_dataset", "dx_load_table", "dx_unload_all",
     "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
-    "dx_result_virtual_term", "dx_result_device_ms", "dx_result_free",
+    "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library():
         "dx_result_column_name": (c_char_p, [c_void_p, c_int]),
         "dx_result_fetch_ids": (c_int, [c_void_p, i64p, c_int]),
         "dx_result_virtual_term": (c_char_p, [c_void_p, c_int64]),
+        "dx_result_plan": (c_char_p, [c_void_p]),
         "dx_result_device_ms": (c_double, [c_void_p]),
         "dx_result_free": (None, [c_void_p]),
     }
@@ -132,6 +133,7 @@ class QueryResult:
         self.count = int(lib.dx_result_count(handle))
         self.columns = [lib.dx_result_column_name(handle, i).decode() for i in range(lib.dx_result_columns(handle))]
         self.device_ms = float(lib.dx_result_device_ms(handle))
+        self.plan = lib.dx_result_plan(handle).decode()
 
     def ids(self, sort=False):
         """(count, n_columns) int64 array of term ids (needs DX_QUERY_BINDINGS)."""
