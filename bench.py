@@ -136,11 +136,13 @@ def main():
 
     from opus_amd import lubm
     from opus_amd.engine import DX_QUERY_COUNT, Engine
+    from opus_amd.host import shard
+    device = torch.device("cuda", local_rank)
 
     # ---- synthetic input, resident in HBM before anything is timed
     ontology = 0
-    u0 = rank * args.universities
-    arr, n_triples = lubm.generate(u0, u0 + args.universities, seed=0, ontology=ontology, degree_pool=1000)
+    u0, u1 = shard.university_block(rank, world, args.universities)
+    arr, n_triples = lubm.generate(u0, u1, seed=0, ontology=ontology, degree_pool=1000)
     text = torch.from_numpy(arr).to("cuda:%d" % local_rank)
     n_bytes = int(arr.size)
     del arr
@@ -176,10 +178,7 @@ def main():
         return times, counts, dev
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(device)
 
     for w in range(args.warmup):
         partition()
@@ -198,15 +197,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_begin
 
-    if world > 1:
-        tt = torch.tensor([elapsed, sum(part_s)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, part_total = tt.tolist()
-        nt = torch.tensor([n_triples], device="cuda", dtype=torch.int64)
-        dist.all_reduce(nt)
-        total_triples = int(nt.item())
-    else:
-        part_total, total_triples = sum(part_s), n_triples
+    elapsed, part_total, total_triples = shard.combine_timings(elapsed, sum(part_s), n_triples, device)
+    counts = shard.combine_counts({n: int(counts[n]) for n in qnames}, device)
 
     if rank == 0:
         med = lambda xs: float(np.median(xs))  # noqa: E731

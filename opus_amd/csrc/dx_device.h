@@ -9,7 +9,7 @@ namespace dx {
 constexpr int kWave = 64;
 
 // ---- term hash ------------------------------------------------------------------------------
-// Two murmur3-style 32-bit lanes fed with the term's bytes four at a time (little-endian words
+// Two murmur-style 32-bit lanes fed with the term's bytes four at a time (little-endian words
 // counted from the term's first byte; a final partial word is zero-padded), finalised together with
 // the length into one 64-bit word. The same code runs on the host (query constants, class-index
 // entries) and on the device (tokeniser, lookups). A hash is only a bucket choice: every dictionary
@@ -21,12 +21,11 @@ struct TermHash {
       : a(0x9747B28Cu ^ (uint32_t)seed), b(0x85EBCA6Bu ^ (uint32_t)(seed >> 32)) {}
   static __host__ __device__ inline uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
   __host__ __device__ inline void add_word(uint32_t k) {
-    uint32_t k1 = k * 0xCC9E2D51u;
-    k1 = rotl(k1, 15) * 0x1B873593u;
-    a = rotl(a ^ k1, 13) * 5u + 0xE6546B64u;
-    uint32_t k2 = k * 0x85EBCA77u;
-    k2 = rotl(k2, 13) * 0xC2B2AE3Du;
-    b = rotl(b ^ k2, 17) * 5u + 0x561CCD1Bu;
+    // one multiply per lane and word (v_mul_lo_u32 is quarter rate); x * 5 + c is a shift-add
+    a = rotl(a ^ rotl(k * 0xCC9E2D51u, 15), 13);
+    a = (a << 2) + a + 0xE6546B64u;
+    b = rotl(b ^ rotl(k * 0x85EBCA77u, 13), 17);
+    b = (b << 2) + b + 0x561CCD1Bu;
   }
   __host__ __device__ inline uint64_t finish(uint32_t len) const {
     uint64_t h = ((uint64_t)a << 32) | (uint64_t)(b ^ len);

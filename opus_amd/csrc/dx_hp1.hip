@@ -229,25 +229,26 @@ __device__ __forceinline__ uint8_t lds_byte(const uint32_t* win, uint32_t pos) {
   return (uint8_t)(win[pos >> 2] >> ((pos & 3) * 8));
 }
 
-// Scans a subject/predicate field starting at pos: returns its end (the first delimiter) and feeds its
-// bytes to h. odd = true when the record needs the slow path. One LDS word is read per four bytes: the
-// upper word of each unaligned read is carried over as the lower word of the next.
-__device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos, uint32_t limit, TermHash& h, bool& odd) {
+// Scans a subject/predicate field starting at pos and feeds its bytes to h; returns the position of the
+// byte that ended it (the first byte <= 0x20). The loop has one exit and no bound of its own: the staged
+// window is followed by line-feed padding, so it stops at the latest there. One LDS word is read per
+// four bytes: the upper word of each unaligned read is carried over as the lower word of the next.
+__device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos, TermHash& h) {
   uint32_t i = pos >> 2;
   const uint32_t sh = pos & 3;
-  uint32_t lo = win[i];
+  uint32_t lo = win[i], v, m;
   for (;;) {
-    if (4 * i + sh + 4 > limit) { odd = true; return 4 * i + sh; }
     const uint32_t hi = win[i + 1];
-    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
-    const uint32_t m = le20_mask(v);
-    if (!m) { h.add_word(v); ++i; lo = hi; continue; }
-    const int k = (__ffs((int)m) - 1) >> 3;
-    const uint8_t c = (uint8_t)(v >> (8 * k));
-    if (!(is_jws(c) || is_eol(c))) { odd = true; return 4 * i + sh; }  // control character inside a token
-    if (k) h.add_word(v & ((1u << (8 * k)) - 1u));
-    return 4 * i + sh + k;
+    v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    m = le20_mask(v);
+    if (m) break;
+    h.add_word(v);
+    ++i;
+    lo = hi;
   }
+  const uint32_t k = (uint32_t)(__ffs((int)m) - 1) >> 3;
+  if (k) h.add_word(v & ((1u << (8 * k)) - 1u));
+  return 4 * i + sh + k;
 }
 
 __global__ void __launch_bounds__(TK_THREADS)
@@ -355,67 +356,64 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     const uint32_t p0 = starts[lr];
     const uint64_t gstart = tile0 + (p0 - TK_PRE);
     RecordOut out;
-    bool odd = false;
     out.bad = false;
+    // Fast path: "<s> <p> <o> ." shaped lines. Anything else -- a field ended by something that is not
+    // blank, control characters, a line that is too short or runs past the window, non-ASCII bytes where
+    // the last two units are cut -- is left to the reference-exact slow path, which also reports errors.
+    bool odd = false;
     uint32_t b[3], e[3];
-    // subject
     TermHash hs(seed), hp(seed), ho(seed);
     b[0] = p0;
-    e[0] = scan_token(win, p0, limit + 4, hs, odd);
+    e[0] = scan_token(win, p0, hs);
     uint32_t p = e[0];
+    odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
+    ++p;
+    if (lds_byte(win, p) <= 0x20) {  // more than one blank between the fields: rare
+      while (p < limit && is_jws(lds_byte(win, p))) ++p;
+      odd |= lds_byte(win, p) <= 0x20;
+    }
+    b[1] = p;
+    e[1] = scan_token(win, p, hp);
+    p = e[1];
+    odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
+    ++p;
+    if (lds_byte(win, p) <= 0x20) {
+      while (p < limit && is_jws(lds_byte(win, p))) ++p;
+      odd |= (lds_byte(win, p) <= 0x20) & !is_eol(lds_byte(win, p));  // an empty object is fine
+    }
+    b[2] = p;
+    {  // end of line: first LF / CR at or after the object's first byte
+      uint32_t i = p >> 2;
+      const uint32_t sh = p & 3;
+      uint32_t lo = win[i], v, m;
+      for (;;) {
+        const uint32_t hi = win[i + 1];
+        v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        m = eol_candidates(v);
+        if (m) break;
+        ++i;
+        lo = hi;
+      }
+      const uint32_t k = (uint32_t)(__ffs((int)m) - 1) >> 3;
+      odd |= !is_eol((uint8_t)(v >> (8 * k)));  // a VT / FF inside the object
+      e[2] = 4 * i + sh + k;
+    }
+    odd |= (e[2] > limit) | ((e[2] == limit) & !window_is_eof);  // the line runs past the staged window
     if (!odd) {
-      if (is_eol(lds_byte(win, p)) || p >= limit) { out.bad = !(p >= limit && !window_is_eof); odd = !out.bad; }
-    }
-    if (!odd && !out.bad) {
-      while (p < limit && is_jws(lds_byte(win, p))) ++p;
-      b[1] = p;
-      e[1] = scan_token(win, p, limit + 4, hp, odd);
-      p = e[1];
-      if (!odd && (is_eol(lds_byte(win, p)) || p >= limit)) { out.bad = !(p >= limit && !window_is_eof); odd = !out.bad; }
-    }
-    if (!odd && !out.bad) {
-      while (p < limit && is_jws(lds_byte(win, p))) ++p;
-      b[2] = p;
-      // end of line
-      uint32_t q = p;
-      bool found = false;
-      {
-        uint32_t i = q >> 2;
-        const uint32_t sh = q & 3;
-        uint32_t lo = win[i];
-        while (!found) {
-          if (q >= limit) break;
-          const uint32_t hi = win[i + 1];
-          const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
-          uint32_t m = eol_candidates(v);
-          while (m) {
-            const int k = (__ffs((int)m) - 1) >> 3;
-            m &= m - 1;
-            if (is_eol((uint8_t)(v >> (8 * k)))) { q += k; found = true; break; }
-          }
-          if (!found) { q += 4; ++i; lo = hi; }
-        }
+      // dropRight(2) then trim
+      if (e[2] - b[2] >= 2) {
+        odd |= ((lds_byte(win, e[2] - 1) | lds_byte(win, e[2] - 2)) & 0x80) != 0;
+        e[2] -= 2;
+      } else {
+        e[2] = b[2];
       }
-      if (!found) { q = limit; if (!window_is_eof) odd = true; }  // the line runs past the staged window
-      if (q > limit) q = limit;
-      e[2] = q;
-      if (!odd) {
-        // dropRight(2) then trim; non-ASCII bytes at the cut go to the slow path
-        if (e[2] - b[2] >= 2) {
-          if ((lds_byte(win, e[2] - 1) | lds_byte(win, e[2] - 2)) & 0x80) odd = true;
-          e[2] -= 2;
-        } else {
-          e[2] = b[2];
-        }
-        while (e[2] > b[2] && lds_byte(win, e[2] - 1) <= 0x20) --e[2];
-        while (b[2] < e[2] && lds_byte(win, b[2]) <= 0x20) ++b[2];
-      }
+      while (e[2] > b[2] && lds_byte(win, e[2] - 1) <= 0x20) --e[2];
+      while (b[2] < e[2] && lds_byte(win, b[2]) <= 0x20) ++b[2];
     }
     if (odd) {
       tokenise_record_slow(text, n, gstart, seed, out);
-    } else if (!out.bad) {
-      // object hash
-      {
+    } else {
+      {  // object hash
         uint32_t q = b[2], i = q >> 2;
         const uint32_t sh = q & 3;
         uint32_t lo = win[i];

@@ -1,0 +1,61 @@
+"""The N>1 host path on CPU: two gloo ranks shard the input, work on their blocks, combine measurements."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from opus_amd import lubm
+        from opus_amd.host import shard
+        from oracle import cpu_port
+        dev = torch.device("cpu")
+        b, e = shard.university_block(rank, world, 1)
+        arr, nt = lubm.generate(b, e, seed=3, degree_pool=5)
+        ci = lubm.class_index_text(4, 0)
+        res = cpu_port.run(arr, ci, 4)  # the rank's local work, done here by the CPU checker
+        shard.barrier(dev)
+        elapsed, part, total = shard.combine_timings(1.0 + rank, 0.5 + 0.25 * rank, nt, dev)
+        counts = shard.combine_counts({"rows": sum(res["part_rows"]), "triples": res["n_triples"]}, dev)
+        out.put((rank, b, e, nt, bytes(arr[:64]), elapsed, part, total, counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_and_combine():
+    from opus_amd import lubm
+    from opus_amd.host import shard
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole, n_whole = lubm.generate(0, 2, seed=3, degree_pool=5)
+    (r0, b0, e0, n0, head0, el0, pt0, tot0, c0), (r1, b1, e1, n1, head1, el1, pt1, tot1, c1) = got
+    assert (b0, e0, b1, e1) == (0, 1, 1, 2)                       # blocks tile the input
+    assert n0 + n1 == n_whole and head0 == bytes(whole[:64])      # and concatenate to the unsharded text
+    assert el0 == el1 == 2.0 and pt0 == pt1 == 0.75               # MAX over ranks
+    assert tot0 == tot1 == n_whole                                # SUM over ranks
+    assert c0 == c1 and c0["triples"] == n_whole
+    assert [shard.partition_owner(q, 2) for q in range(5)] == [0, 1, 0, 1, 0]
+    with pytest.raises(ValueError):
+        shard.university_block(2, 2, 1)
