@@ -219,18 +219,23 @@ class Engine:
     def term_count(self) -> int:
         return int(self.lib.dx_term_count(self.ctx))
 
-    def decode(self, ids) -> list:
+    def decode_raw(self, ids):
+        """(bytes as a uint8 array, n+1 offsets): term k of `ids` is bytes[offs[k]:offs[k+1]]."""
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         n = ids.size
-        if n == 0:
-            return []
         total = c_uint64(0)
-        self._check(self.lib.dx_terms_bytes(self.ctx, _p(ids), n, byref(total)))
-        buf = ctypes.create_string_buffer(max(1, total.value))
-        offs = np.empty(n + 1, dtype=np.uint64)
-        self._check(self.lib.dx_terms_decode(self.ctx, _p(ids), n, buf, total.value, _p(offs, c_uint64)))
-        raw = buf.raw
-        return [raw[int(offs[i]):int(offs[i + 1])].decode("utf-8", "surrogateescape") for i in range(n)]
+        if n:
+            self._check(self.lib.dx_terms_bytes(self.ctx, _p(ids), n, byref(total)))
+        buf = np.empty(max(1, total.value), dtype=np.uint8)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            self._check(self.lib.dx_terms_decode(self.ctx, _p(ids), n, buf.ctypes.data_as(c_void_p), total.value, _p(offs, c_uint64)))
+        return buf[:total.value], offs
+
+    def decode(self, ids) -> list:
+        buf, offs = self.decode_raw(ids)
+        raw = buf.tobytes()
+        return [raw[int(offs[i]):int(offs[i + 1])].decode("utf-8", "surrogateescape") for i in range(len(offs) - 1)]
 
     def lookup(self, terms) -> np.ndarray:
         enc = [t.encode("utf-8", "surrogateescape") for t in terms]

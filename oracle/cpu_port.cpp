@@ -203,4 +203,15 @@ void cpu_port_stats(void* h, uint64_t* out) {
   for (size_t i = 0; i < r->part_rows.size(); ++i) { out[6 + i] = r->part_rows[i]; out[6 + r->part_rows.size() + i] = r->part_digest[i]; }
 }
 void cpu_port_free(void* h) { delete (Result*)h; }
+// Digest of rows given as ids into a string pool (term i = pool[offs[i], offs[i+1])): the same sum run() forms
+// for a partition, so that a checker can compare id-encoded rows with this restatement without decoding them.
+uint64_t cpu_port_rows_digest(const uint8_t* pool, const uint64_t* offs, uint64_t n_terms, const int64_t* s, const int64_t* o,
+                              const int64_t* p, uint64_t n_rows) {
+  std::vector<uint64_t> h(n_terms);
+  for (uint64_t i = 0; i < n_terms; ++i) h[i] = fnv(sv((const char*)pool + offs[i], offs[i + 1] - offs[i]));
+  uint64_t d = 0;
+  for (uint64_t r = 0; r < n_rows; ++r)
+    d += mix(h[s[r]] ^ mix(h[o[r]] + 0x9E3779B97F4A7C15ull) ^ mix(h[p[r]] + 0x632BE59BD9B4E019ull));
+  return d;
+}
 }

@@ -16,6 +16,9 @@ def _lib():
         lib.cpu_port_run.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.cpu_port_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.cpu_port_free.argtypes = [ctypes.c_void_p]
+        lib.cpu_port_rows_digest.restype = ctypes.c_uint64
+        lib.cpu_port_rows_digest.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_uint64]
         _LIB = lib
     return _LIB
 
@@ -57,3 +60,12 @@ def run(text_u8: np.ndarray, class_index_text: str, n_partitions: int) -> dict:
             "n_node_index": int(out[4]), "n_tables": int(out[5]),
             "part_rows": [int(x) for x in out[6:6 + n_partitions]],
             "part_digest": [int(x) for x in out[6 + n_partitions:6 + 2 * n_partitions]]}
+
+
+def rows_digest(pool: np.ndarray, offs: np.ndarray, s: np.ndarray, o: np.ndarray, p: np.ndarray) -> int:
+    """Digest of id-encoded rows over a string pool (term i = pool[offs[i]:offs[i+1]]), comparable with part_digest."""
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    s, o, p = (np.ascontiguousarray(a, dtype=np.int64) for a in (s, o, p))
+    return int(_lib().cpu_port_rows_digest(pool.ctypes.data, offs.ctypes.data, offs.size - 1, s.ctypes.data, o.ctypes.data,
+                                           p.ctypes.data, s.size))

@@ -66,7 +66,12 @@ class SqliteProcessor:
             if name not in self.loaded:
                 self.db.execute('CREATE TABLE "%s" (s TEXT, o TEXT)' % name)
                 self.db.executemany('INSERT INTO "%s" VALUES (?, ?)' % name, rows)
+                # indexes and statistics change SQLite's plan, never its answer: without them its join order
+                # for the six-pattern triangles takes minutes on a few hundred thousand rows
+                self.db.execute('CREATE INDEX "%s_s" ON "%s" (s)' % (name, name))
+                self.db.execute('CREATE INDEX "%s_o" ON "%s" (o)' % (name, name))
                 self.loaded.add(name)
+                self.analysed = False
             rows_total += len(rows)
         return rows_total
 
@@ -75,6 +80,9 @@ class SqliteProcessor:
         if len(query_map) != 1:
             raise NotImplementedError("multi-statement files are never produced by the translator")
         sql = _strip_union_parens(next(iter(query_map.values())))
+        if not getattr(self, "analysed", True):
+            self.db.execute("ANALYZE")
+            self.analysed = True
         cur = self.db.execute(sql)
         cols = [d[0] for d in cur.description]
         return cols, cur.fetchall()

@@ -1,0 +1,144 @@
+"""Parity beyond the hand-sized cases: heterogeneous schemas against the Python restatement, and the
+benchmark's own sizes against the C++ restatement through order-independent digests plus the
+size-independent properties of the output (sorted duplicate-free tables, idempotence, id round trips)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from opus_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _digests(e):
+    """Per-partition digest of the engine's rows, formed over its own string pool."""
+    from oracle import cpu_port
+    pool, offs = e.decode_raw(np.arange(e.term_count(), dtype=np.int64))
+    out, rows = [], []
+    for q in range(e.partition_count()):
+        s, o, p = e.partition_rows(q)
+        rows.append(len(s))
+        out.append(cpu_port.rows_digest(pool, offs, s, o, p))
+    return rows, out
+
+
+def _check_against_cpu_port(e, arr, ci, n, st):
+    from oracle import cpu_port
+    ref = cpu_port.run(arr, ci, n)
+    assert st.n_triples == ref["n_triples"]
+    assert st.n_vertices == ref["n_vertices"]
+    assert st.n_edges == ref["n_edges"]
+    assert st.n_node_index == ref["n_node_index"]
+    rows, dig = _digests(e)
+    assert rows == ref["part_rows"]
+    assert dig == ref["part_digest"]
+    return ref
+
+
+def _check_table_properties(e, st, max_tables=40):
+    """Every VP table is a slice of its partition, strictly increasing in (s, o): sorted and duplicate-free."""
+    tabs = e.tables()
+    assert sum(t["rows"] for t in tabs) == st.n_rows
+    per_part = {}
+    for t in tabs:
+        per_part[t["partition"]] = per_part.get(t["partition"], 0) + t["rows"]
+    for q in range(e.partition_count()):
+        assert per_part.get(q, 0) == len(e.partition_rows(q)[0])
+    for t in sorted(tabs, key=lambda t: -t["rows"])[:max_tables]:
+        s, o = e.table_rows(t["index"], t["rows"])
+        ds, do = np.diff(s), np.diff(o)
+        assert np.all((ds > 0) | ((ds == 0) & (do > 0))), "table %d is not strictly sorted" % t["index"]
+
+
+@pytest.mark.parametrize("shape,n", [("swdf", 20000), ("dbpedia", 40000)])
+def test_heterogeneous_schema_against_python_oracle(engine, shape, n):
+    """Hundreds to thousands of predicates (more than 256 tables per partition), multi-typed subjects,
+    classes missing from the index, predicates of 150 characters and more, look-alike directory names,
+    tabs / runs of blanks / CRLF on some lines."""
+    from opus_amd.workloads import hetero
+    from oracle import dap_oracle
+    from parity_util import assert_same_as_oracle, engine_artifacts
+    text, ci, k = hetero.generate(shape, n, seed=0)
+    st = engine.partition_text(text.encode(), ci, k)
+    ref = dap_oracle.run_dap(text, ci, k)
+    assert st.n_triples == ref["n_triples"] == n
+    assert_same_as_oracle(engine_artifacts(engine), ref)
+    if shape == "dbpedia":
+        assert st.n_predicates > 2000 and st.n_tables > 256 * k
+
+
+def test_dbpedia_shaped_1m_against_cpu_port(engine):
+    from opus_amd.workloads import hetero
+    text, ci, k = hetero.generate("dbpedia", 1_000_000, seed=1)
+    arr = np.frombuffer(text.encode(), dtype=np.uint8)
+    st = engine.partition_text(arr, ci, k)
+    _check_against_cpu_port(engine, arr, ci, k, st)
+    _check_table_properties(engine, st)
+
+
+def test_lubm100_benchmark_size(engine):
+    """The benchmark's workload itself: digests against the C++ restatement, table properties,
+    idempotence of a second run and the id <-> term round trip."""
+    from opus_amd import lubm
+    arr, n_triples = lubm.generate(0, 100, seed=0, ontology=0)
+    ci = lubm.class_index_text(8, 0)
+    st = engine.partition_text(arr, ci, 8)
+    assert st.n_triples == n_triples
+    _check_against_cpu_port(engine, arr, ci, 8, st)
+    _check_table_properties(engine, st, max_tables=12)
+    first = [tuple(a.copy() for a in engine.partition_rows(q)) for q in (0, 5)]
+    ids = np.random.default_rng(3).integers(0, engine.term_count(), size=2000)
+    terms = engine.decode(ids)
+    assert np.array_equal(engine.lookup(terms), ids)
+    assert np.all(engine.lookup(["<http://nowhere/x>", '"no such literal"']) == -1)
+    st2 = engine.partition_text(arr, ci, 8)
+    assert (st2.n_rows, st2.n_terms, st2.n_vp_index) == (st.n_rows, st.n_terms, st.n_vp_index)
+    for q, (s, o, p) in zip((0, 5), first):
+        s2, o2, p2 = engine.partition_rows(q)
+        assert np.array_equal(s, s2) and np.array_equal(o, o2) and np.array_equal(p, p2)
+
+
+def test_lubm10_queries_against_sqlite(engine):
+    """All 13 queries on ten universities: the partitions are pinned by digest, then SQLite runs the same
+    translated SQL over the decoded tables; counts for all, sorted bindings where the result is small."""
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_BINDINGS
+    from opus_amd.host import translator as T
+    from oracle import dap_oracle
+    from oracle.query_oracle import parse_translated_file, run_query
+    arr, _ = lubm.generate(0, 10, seed=0, ontology=0, degree_pool=10)
+    ci = lubm.class_index_text(8, 0)
+    st = engine.partition_text(arr, ci, 8)
+    _check_against_cpu_port(engine, arr, ci, 8, st)
+    strs = engine.decode(np.arange(engine.term_count(), dtype=np.int64))
+    vp, stat = {}, {}
+    for t in engine.tables():
+        s, o = engine.table_rows(t["index"], t["rows"])
+        name = dap_oracle.partition_name(t["partition"])
+        vp[(name, "_3=" + dap_oracle.uri_to_storage(strs[t["predicate"]]))] = [(strs[a], strs[b]) for a, b in zip(s.tolist(), o.tolist())]
+        stat[name] = stat.get(name, 0) + t["rows"]
+    ni = {}
+    u, c = engine.node_index()
+    for a, b in zip(u.tolist(), c.tolist()):
+        ni.setdefault(strs[a], []).append(strs[b])
+    cidx = T.load_class_index(ci)
+    for name, text in lubm.queries(0).items():
+        tr = T.translate_query(name, text, lambda x: ni.get(x, []), cidx, stat)
+        assert tr is not None, name
+        ref = run_query(vp, tr)
+        qm, partitions, _ = parse_translated_file(tr)
+        engine.unload_all()
+        assert sum(engine.load_table(p) for p in partitions) == ref["load_data"]
+        sql = next(iter(qm.values()))
+        assert engine.query(sql).count == ref["count"], name
+        if ref["count"] <= 20000:
+            res = engine.query(sql, DX_QUERY_BINDINGS)
+            rows, cols = res.rows()
+            assert cols == ref["columns"] and rows == ref["rows"], name
