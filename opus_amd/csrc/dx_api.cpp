@@ -346,16 +346,19 @@ int dx_node_index_fetch(dx_ctx* ctx, int64_t* uri, int64_t* type) {
 
 int64_t dx_vp_index_rows(dx_ctx* ctx, int q) {
   if (!ctx || !ctx->part.valid || q < 0 || q >= ctx->part.n_partitions) return -1;
-  return (int64_t)(ctx->part.vpi_base[q + 1] - ctx->part.vpi_base[q]);
+  const PartitionState& ps = ctx->part;
+  return (int64_t)((ps.vpi_s_base[q + 1] - ps.vpi_s_base[q]) + (ps.vpi_o_base[q + 1] - ps.vpi_o_base[q]));
 }
 
 int dx_vp_index_fetch(dx_ctx* ctx, int q, int64_t* uri, int32_t* role, int64_t* predicate) {
   return guard(ctx, [&] {
     const PartitionState& ps = ctx->part;
     if (!ps.valid || q < 0 || q >= ps.n_partitions) throw DxError(DX_E_INVAL, "no such partition");
-    const uint64_t b = ps.vpi_base[q], n = ps.vpi_base[q + 1] - b;
+    const uint64_t bs = ps.vpi_s_base[q], ns = ps.vpi_s_base[q + 1] - bs, bo = ps.vpi_o_base[q], no = ps.vpi_o_base[q + 1] - bo;
+    const uint64_t n = ns + no;
     std::vector<uint64_t> k(n);
-    fetch(k.data(), ps.vpi.p + b, n * 8);
+    if (ns) fetch(k.data(), ps.vpi_s.p + bs, ns * 8);
+    if (no) fetch(k.data() + ns, ps.vpi_o.p + bo, no * 8);
     const uint64_t pm = (1ull << ps.vpi_bits_pred) - 1, tm = (1ull << ps.vpi_bits_term) - 1;
     for (uint64_t i = 0; i < n; ++i) {
       predicate[i] = ps.pred_terms[k[i] & pm];
@@ -510,7 +513,7 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
     // VP index (DAP.scala:450-501)
     for (int q = 0; q < ps.n_partitions; ++q) {
       if (ps.part_base[q + 1] == ps.part_base[q]) continue;
-      const uint64_t n = ps.vpi_base[q + 1] - ps.vpi_base[q];
+      const uint64_t n = (uint64_t)dx_vp_index_rows(ctx, q);
       std::vector<int64_t> u(n), pr(n), rl(n);
       std::vector<int32_t> r32(n);
       if (n) {

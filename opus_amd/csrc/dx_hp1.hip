@@ -564,26 +564,34 @@ k_dict_assign(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t
   term_src[id] = t_rep[i] >> kRepLenBits;
 }
 
-// Encoded records (s, p, o as term ids) + per-term flags that follow from the record kinds.
+// Encoded records (s, p, o as term ids) + per-term facts that follow from the record kinds. Each fact has
+// a byte array of its own, written with plain stores of 1: every writer of a byte stores the same value, so
+// no atomics are needed (read-modify-write atomics are carried out lane by lane in the L2, and the records
+// of one subject sit in neighbouring lanes). The check before each store only saves stores.
 __global__ void __launch_bounds__(256)
 k_encode(const uint32_t* __restrict__ t_slot, const DictSlot* __restrict__ ht, const uint8_t* __restrict__ kind,
          uint32_t n_rec, uint32_t* __restrict__ S, uint32_t* __restrict__ P, uint32_t* __restrict__ O,
-         uint8_t* __restrict__ term_flags, uint8_t* __restrict__ is_pred) {
+         uint8_t* __restrict__ is_vertex, uint8_t* __restrict__ has_edge, uint8_t* __restrict__ is_literal,
+         uint8_t* __restrict__ is_pred) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rec) return;
   const uint32_t s = (uint32_t)ht[t_slot[r]].val, p = (uint32_t)ht[t_slot[(uint64_t)n_rec + r]].val,
                  o = (uint32_t)ht[t_slot[2ull * n_rec + r]].val;
   S[r] = s; P[r] = p; O[r] = o;
-  is_pred[p] = 1;
+  auto set = [](uint8_t* a, uint32_t id) { if (!a[id]) a[id] = 1; };
+  set(is_pred, p);
   const uint8_t k = kind[r];
-  // benign races: concurrent writers OR constant bits into a byte through atomicOr on the containing word
-  auto set_flag = [&](uint32_t id, uint8_t f) {
-    uint32_t* w = reinterpret_cast<uint32_t*>(term_flags) + (id >> 2);
-    const uint32_t bit = (uint32_t)f << ((id & 3) * 8);
-    if ((*w & bit) != bit) atomicOr(w, bit);
-  };
-  if (k == 0) { set_flag(s, kFlagVertex | kFlagEdge); set_flag(o, kFlagVertex | kFlagEdge); }
-  else { set_flag(s, kFlagVertex); if (k == 2) set_flag(o, kFlagLiteral); }
+  set(is_vertex, s);
+  if (k == 0) { set(has_edge, s); set(is_vertex, o); set(has_edge, o); }
+  else if (k == 2) set(is_literal, o);
+}
+
+__global__ void __launch_bounds__(256)
+k_merge_flags(const uint8_t* __restrict__ is_vertex, const uint8_t* __restrict__ has_edge, const uint8_t* __restrict__ is_literal,
+              uint32_t n_terms, uint8_t* __restrict__ flags) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_terms)
+    flags[t] = (is_vertex[t] ? kFlagVertex : 0) | (has_edge[t] ? kFlagEdge : 0) | (is_literal[t] ? kFlagLiteral : 0);
 }
 
 // Copies term bytes from the input text into the id-ordered pool: one thread per term, 16 bytes at a
@@ -675,11 +683,10 @@ __global__ void __launch_bounds__(256)
 k_list_preds(const uint8_t* __restrict__ is_pred, const uint32_t* __restrict__ pred_index, const uint8_t* __restrict__ flags,
              uint32_t n_terms, uint32_t* __restrict__ pred_terms, unsigned long long* __restrict__ n_vertices) {
   __shared__ uint32_t lds[8];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t v = 0;
-  if (t < n_terms) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_terms; t += gridDim.x * blockDim.x) {
     if (is_pred[t]) pred_terms[pred_index[t]] = t;
-    v = (flags[t] & kFlagVertex) ? 1u : 0u;
+    v += (flags[t] & kFlagVertex) ? 1u : 0u;
   }
   uint32_t total;
   (void)block_excl_scan_256<uint32_t>(v, lds, total);
@@ -707,14 +714,15 @@ __global__ void __launch_bounds__(256)
 k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
         const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, uint64_t* __restrict__ mask,
         uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges*/) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  // Grid-stride: the two counters are hit once per block at the end, and the grid is a few thousand blocks.
+  // (Atomics of many blocks on one word are served one after another by a single L2 channel.)
   uint32_t uq = 0, ed = 0;
-  if (i < n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint64_t k = keys[i];
     uint64_t m = 0;
     uint8_t nf = 0;
     if (i == 0 || keys[i - 1] != k) {
-      uq = 1;
+      ++uq;
       const Unpacked t = unpack(k, bits_term);
       if (t.pidx == type_pidx) {
         m = (flags[t.s] & kFlagEdge) ? Pm[t.o] : 0;
@@ -722,7 +730,7 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
       } else if (flags[t.o] & kFlagLiteral) {
         m = (flags[t.s] & kFlagEdge) ? M[t.s] : 0;
       } else {
-        ed = 1;
+        ++ed;
         m = M[t.s] | M[t.o];
       }
     }
@@ -733,7 +741,7 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
   uint32_t tu, te;
   (void)block_excl_scan_256<uint32_t>(uq, lds, tu);
   (void)block_excl_scan_256<uint32_t>(ed, lds, te);
-  if (threadIdx.x == 0) {  // one pair of atomics per block: thousands of waves hitting one word serialise
+  if (threadIdx.x == 0) {
     if (tu) atomicAdd(&counters[0], (unsigned long long)tu);
     if (te) atomicAdd(&counters[1], (unsigned long long)te);
   }
@@ -833,20 +841,26 @@ k_node_index(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ node
   const Unpacked t = unpack(keys[i], bits_term);
   ns[pos[i]] = t.s;
   no[pos[i]] = t.o;
-  uint32_t* w = reinterpret_cast<uint32_t*>(flags) + (t.s >> 2);
-  const uint32_t bit = (uint32_t)kFlagNode << ((t.s & 3) * 8);
-  if (!(*w & bit)) atomicOr(w, bit);
+  // plain byte store: nothing else writes the flags while this kernel runs, and every writer of this byte
+  // (the other node-index rows of the same uri) stores the same value
+  const uint8_t f = flags[t.s];
+  if (!(f & kFlagNode)) flags[t.s] = f | kFlagNode;
 }
 
-// For each row of each partition, the entries it contributes to the partition's VP index
-// (DAP.scala:479-497): (s, 's', p) when s is a typed uri (has a node-index row), (o, 'o', p) when o is
-// one, and (o, 'o', rdf:type) for every type row. An 's' entry equal to the previous row's is skipped
-// (rows are sorted by (p, s)), the rest of the duplicates fall to the sort.
-template <bool WRITE>
+// The VP index of a partition (DAP.scala:479-497) is the set of (uri, role, predicate) with uri a typed
+// uri (one that has a node-index row) standing as subject ('s') or object ('o') of a row of that predicate,
+// plus (class, 'o', rdf:type) for every type row. Rows are sorted by (partition, predicate, s, o), so:
+//  - 's' entries are distinct as soon as a row whose (predicate, s) equals the previous row's is skipped,
+//    and they come out in (partition, predicate, s) order: no sort;
+//  - 'o' entries of non-type rows need a sort to drop duplicates;
+//  - the classes of type rows are few and repeat millions of times: a type row (s, C) lies in every
+//    partition of the class index entry of C, so marking C as used (a plain byte store) is enough, and the
+//    entries (C, 'o', rdf:type) of the partitions of C are written afterwards.
+// Pass 1 writes the per-row decisions es/eo, pass 2 (after the scans) writes the entries.
 __global__ void __launch_bounds__(256)
-k_vpi_emit(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
-           const uint32_t* __restrict__ part_base, int nparts, uint32_t type_pidx, const uint8_t* __restrict__ flags,
-           int bits_term, int bits_pred, uint8_t* __restrict__ cnt, const uint32_t* __restrict__ pos, uint64_t* __restrict__ out) {
+k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
+            const uint32_t* __restrict__ part_base, int nparts, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+            uint8_t* __restrict__ es_out, uint8_t* __restrict__ eo_out, uint8_t* __restrict__ class_used) {
   const uint32_t total = part_base[nparts];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -855,12 +869,58 @@ k_vpi_emit(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o,
   const uint32_t s = (uint32_t)row_s[i], o = (uint32_t)row_o[i], p = row_p[i];
   bool es = (flags[s] & kFlagNode) != 0;
   if (es && i > part_base[q] && row_p[i - 1] == p && (uint32_t)row_s[i - 1] == s) es = false;
-  const bool eo = (flags[o] & kFlagNode) != 0 || p == type_pidx;
-  if (!WRITE) { cnt[i] = (uint8_t)es + (uint8_t)eo; return; }
-  uint32_t w = pos[i];
+  bool eo = false;
+  if (p == type_pidx) {
+    if (!class_used[o]) class_used[o] = 1;
+  } else {
+    eo = (flags[o] & kFlagNode) != 0;
+  }
+  es_out[i] = es;
+  eo_out[i] = eo;
+}
+
+__global__ void __launch_bounds__(256)
+k_vpi_write(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
+            const uint32_t* __restrict__ part_base, int nparts, int bits_term, int bits_pred, const uint8_t* __restrict__ es,
+            const uint8_t* __restrict__ eo, const uint32_t* __restrict__ pos_s, const uint32_t* __restrict__ pos_o,
+            uint64_t* __restrict__ out_s, uint64_t* __restrict__ out_o) {
+  const uint32_t total = part_base[nparts];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const bool a = es[i], b = eo[i];
+  if (!a && !b) return;
+  int q = 0;
+  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
   const uint64_t qq = (uint64_t)q << (bits_term + 1 + bits_pred);
-  if (es) out[w++] = qq | ((uint64_t)s << (1 + bits_pred)) | p;
-  if (eo) out[w++] = qq | ((uint64_t)o << (1 + bits_pred)) | (1ull << bits_pred) | p;
+  const uint32_t p = row_p[i];
+  if (a) out_s[pos_s[i]] = qq | ((uint64_t)row_s[i] << (1 + bits_pred)) | p;
+  if (b) out_o[pos_o[i]] = qq | ((uint64_t)row_o[i] << (1 + bits_pred)) | (1ull << bits_pred) | p;
+}
+
+// counts (out == nullptr) or appends the (class, 'o', rdf:type) entries of the classes in use
+__global__ void __launch_bounds__(256)
+k_vpi_type_entries(const uint8_t* __restrict__ class_used, const uint64_t* __restrict__ Pm, uint32_t n_terms, uint32_t type_pidx,
+                   int bits_term, int bits_pred, unsigned long long* __restrict__ counter, uint64_t* __restrict__ out) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_terms; t += gridDim.x * blockDim.x) {
+    if (!class_used[t]) continue;  // all but the class terms
+    unsigned long long m = Pm[t];
+    if (!m) continue;
+    const unsigned long long at = atomicAdd(counter, (unsigned long long)__popcll(m));
+    if (!out) continue;
+    for (uint32_t k = 0; m; ++k, m &= m - 1) {
+      const uint64_t q = (uint64_t)(__ffsll((long long)m) - 1);
+      out[at + k] = (q << (bits_term + 1 + bits_pred)) | ((uint64_t)t << (1 + bits_pred)) | (1ull << bits_pred) | type_pidx;
+    }
+  }
+}
+
+// base[q] = pos[part_base[q]] for q < nparts (an empty partition takes the next one's), base[nparts] = total
+__global__ void k_vpi_s_bases(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ part_base, int nparts, uint32_t n_rows,
+                              const uint32_t* __restrict__ total, uint32_t* __restrict__ base) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > nparts) return;
+  const uint32_t r = part_base[q];
+  base[q] = (q == nparts || r >= n_rows) ? *total : pos[r];
 }
 
 __global__ void __launch_bounds__(256)
@@ -1057,6 +1117,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   // 4 slots per record can never overflow (at most 3 distinct terms per record).
   uint64_t cap = 1024;
   while (cap < n_rec + n_rec / 2) cap <<= 1;
+  if (getenv("DX_CAP_SHIFT")) cap >>= atoi(getenv("DX_CAP_SHIFT"));
   DevBuf<DictSlot> ht(pool, cap);
   DevBuf<uint8_t> first(pool, n_occ);
   DevBuf<uint32_t> first_scan(pool, n_occ);
@@ -1118,16 +1179,19 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint64_t> term_src(pool, n_terms);
   DevBuf<uint32_t> S(pool, n_rec), P(pool, n_rec), O(pool, n_rec);
   ps.term_flags = DevBuf<uint8_t>(pool, ((size_t)n_terms + 4) & ~(size_t)3);
-  DevBuf<uint8_t> is_pred(pool, n_terms);
-  DX_HIP(hipMemsetAsync(ps.term_flags.p, 0, ps.term_flags.bytes(), s));
-  DX_HIP(hipMemsetAsync(is_pred.p, 0, n_terms ? n_terms : 1, s));
+  const size_t nt_pad = ((size_t)n_terms + 4) & ~(size_t)3;
+  DevBuf<uint8_t> fact(pool, 4 * nt_pad);  // is_pred, is_vertex, has_edge, is_literal
+  uint8_t* const is_pred = fact.p;
+  DX_HIP(hipMemsetAsync(fact.p, 0, fact.bytes(), s));
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
     hipLaunchKernelGGL(k_dict_assign, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, ht.p,
                        term_len.p, term_src.p);
     hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_slot.p, ht.p, kind.p, n_rec, S.p, P.p, O.p,
-                       ps.term_flags.p, is_pred.p);
+                       fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
   }
+  hipLaunchKernelGGL(k_merge_flags, dim3(blocks(n_terms)), dim3(256), 0, s, fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad,
+                     n_terms, ps.term_flags.p);
   // the build-time table doubles as the lookup table
   d.ht = std::move(ht);
   d.ht_mask = cap - 1;
@@ -1176,7 +1240,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
 
   // ---- 6. predicates, sort keys
   DevBuf<uint32_t> pred_index(pool, (size_t)n_terms + 1);
-  exclusive_scan_u8_u32(pool, is_pred.p, pred_index.p, n_terms, d_total.p, s);
+  exclusive_scan_u8_u32(pool, is_pred, pred_index.p, n_terms, d_total.p, s);
   uint32_t np = 0;
   DX_HIP(hipMemcpyAsync(&np, d_total.p, 4, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
@@ -1186,7 +1250,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DevBuf<unsigned long long> d_nv(pool, 1);
     DX_HIP(hipMemsetAsync(d_nv.p, 0, 8, s));
     if (n_terms)
-      hipLaunchKernelGGL(k_list_preds, dim3(blocks(n_terms)), dim3(256), 0, s, is_pred.p, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
+      hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
     std::vector<uint32_t> hp(np);
     unsigned long long nv = 0;
     if (np) DX_HIP(hipMemcpyAsync(hp.data(), d_preds.p, (size_t)np * 4, hipMemcpyDeviceToHost, s));
@@ -1204,7 +1268,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   ps.uniq = DevBuf<uint64_t>(pool, n_rec);
   ps.n_uniq_slots = n_rec;
   if (n_rec) hipLaunchKernelGGL(k_pack_keys, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, P.p, O.p, n_rec, pred_index.p, bits_term, ps.uniq.p);
-  S.reset(); P.reset(); O.reset(); kind.reset(); is_pred.reset();
+  S.reset(); P.reset(); O.reset(); kind.reset(); fact.reset();
   radix_sort_u64(pool, ps.uniq.p, nullptr, n_rec, bits_pred + 2 * bits_term, s);
   tm.mark();
 
@@ -1214,7 +1278,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<unsigned long long> counters(pool, 2);
   DX_HIP(hipMemsetAsync(counters.p, 0, 16, s));
   if (n_rec)
-    hipLaunchKernelGGL(k_place, dim3(blocks(n_rec)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
+    hipLaunchKernelGGL(k_place, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
                        mask.p, node_flag.p, counters.p);
   tm.mark();
 
@@ -1273,37 +1337,58 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   // ---- 10. VP index
   ps.vpi_bits_term = bits_term;
   ps.vpi_bits_pred = bits_pred;
-  ps.vpi_base.assign(nparts + 1, 0);
+  ps.vpi_s_base.assign(nparts + 1, 0);
+  ps.vpi_o_base.assign(nparts + 1, 0);
   if (n_rows) {
-    DevBuf<uint8_t> cnt(pool, n_rows);
-    DevBuf<uint32_t> pos(pool, n_rows);
-    hipLaunchKernelGGL(k_vpi_emit<false>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
-                       ps.type_pidx, ps.term_flags.p, bits_term, bits_pred, cnt.p, nullptr, nullptr);
-    exclusive_scan_u8_u32(pool, cnt.p, pos.p, n_rows, d_total.p, s);
-    uint32_t n_ent = 0;
-    DX_HIP(hipMemcpyAsync(&n_ent, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DevBuf<uint8_t> es(pool, n_rows), eo(pool, n_rows);
+    DevBuf<uint32_t> pos_s(pool, n_rows), pos_o(pool, n_rows);
+    DevBuf<uint8_t> class_used(pool, n_terms);
+    DevBuf<unsigned long long> n_type_ent(pool, 2);
+    DevBuf<uint32_t> totals(pool, 2);
+    DX_HIP(hipMemsetAsync(class_used.p, 0, class_used.bytes(), s));
+    DX_HIP(hipMemsetAsync(n_type_ent.p, 0, 16, s));
+    hipLaunchKernelGGL(k_vpi_flags, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
+                       ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p);
+    exclusive_scan_u8_u32(pool, es.p, pos_s.p, n_rows, totals.p, s);
+    exclusive_scan_u8_u32(pool, eo.p, pos_o.p, n_rows, totals.p + 1, s);
+    hipLaunchKernelGGL(k_vpi_type_entries, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx, bits_term,
+                       bits_pred, n_type_ent.p, (uint64_t*)nullptr);
+    DevBuf<uint32_t> sb(pool, nparts + 1);
+    hipLaunchKernelGGL(k_vpi_s_bases, dim3(1), dim3(128), 0, s, pos_s.p, d_part_base.p, nparts, n_rows, totals.p, sb.p);
+    uint32_t h_tot[2] = {0, 0};
+    unsigned long long h_type_ent = 0;
+    std::vector<uint32_t> hsb(nparts + 1);
+    DX_HIP(hipMemcpyAsync(h_tot, totals.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(&h_type_ent, n_type_ent.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(hsb.data(), sb.p, (nparts + 1) * 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
-    DevBuf<uint64_t> ent(pool, n_ent);
-    hipLaunchKernelGGL(k_vpi_emit<true>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
-                       ps.type_pidx, ps.term_flags.p, bits_term, bits_pred, nullptr, pos.p, ent.p);
-    cnt.reset(); pos.reset();
-    radix_sort_u64(pool, ent.p, nullptr, n_ent, bits_for(nparts) + bits_term + 1 + bits_pred, s);
-    DevBuf<uint8_t> fl(pool, n_ent);
-    DevBuf<uint32_t> fp(pool, n_ent);
-    if (n_ent) hipLaunchKernelGGL(k_flag_distinct, dim3(blocks(n_ent)), dim3(256), 0, s, ent.p, n_ent, fl.p);
-    exclusive_scan_u8_u32(pool, fl.p, fp.p, n_ent, d_total.p, s);
-    uint32_t n_vpi = 0;
-    DX_HIP(hipMemcpyAsync(&n_vpi, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    const uint32_t n_s = h_tot[0], n_o_raw = h_tot[1] + (uint32_t)h_type_ent;
+    for (int q = 0; q <= nparts; ++q) ps.vpi_s_base[q] = hsb[q];
+    ps.vpi_s = DevBuf<uint64_t>(pool, n_s);
+    DevBuf<uint64_t> ent(pool, n_o_raw);
+    hipLaunchKernelGGL(k_vpi_write, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts, bits_term,
+                       bits_pred, es.p, eo.p, pos_s.p, pos_o.p, ps.vpi_s.p, ent.p);
+    if (h_type_ent)
+      hipLaunchKernelGGL(k_vpi_type_entries, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx, bits_term,
+                         bits_pred, n_type_ent.p + 1, ent.p + h_tot[1]);
+    es.reset(); eo.reset(); pos_s.reset(); pos_o.reset();
+    radix_sort_u64(pool, ent.p, nullptr, n_o_raw, bits_for(nparts) + bits_term + 1 + bits_pred, s);
+    DevBuf<uint8_t> fl(pool, n_o_raw);
+    DevBuf<uint32_t> fp(pool, n_o_raw);
+    if (n_o_raw) hipLaunchKernelGGL(k_flag_distinct, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, n_o_raw, fl.p);
+    exclusive_scan_u8_u32(pool, fl.p, fp.p, n_o_raw, d_total.p, s);
+    uint32_t n_o = 0;
+    DX_HIP(hipMemcpyAsync(&n_o, d_total.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
-    ps.vpi = DevBuf<uint64_t>(pool, n_vpi);
-    if (n_ent) hipLaunchKernelGGL(k_compact_u64, dim3(blocks(n_ent)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_ent, ps.vpi.p);
+    ps.vpi_o = DevBuf<uint64_t>(pool, n_o);
+    if (n_o_raw) hipLaunchKernelGGL(k_compact_u64, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_o_raw, ps.vpi_o.p);
     DevBuf<uint32_t> vb(pool, nparts + 1);
-    hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi.p, n_vpi, bits_term + 1 + bits_pred, nparts, vb.p);
+    hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, n_o, bits_term + 1 + bits_pred, nparts, vb.p);
     std::vector<uint32_t> hvb(nparts + 1);
     DX_HIP(hipMemcpyAsync(hvb.data(), vb.p, (nparts + 1) * 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
-    for (int q = 0; q <= nparts; ++q) ps.vpi_base[q] = hvb[q];
-    st.n_vp_index = n_vpi;
+    for (int q = 0; q <= nparts; ++q) ps.vpi_o_base[q] = hvb[q];
+    st.n_vp_index = (uint64_t)n_s + n_o;
   }
   tm.mark();
   DX_HIP(hipStreamSynchronize(s));

@@ -55,8 +55,11 @@ struct PartitionState {
   DevBuf<int64_t> node_s, node_o;
   uint64_t n_node = 0;
   // VP index: sorted unique keys (partition, uri, role, pidx) packed into 64 bits
-  DevBuf<uint64_t> vpi;
-  std::vector<uint64_t> vpi_base;     // n_partitions + 1
+  // VP index as two lists of packed (partition | term | role | predicate) words: the subject entries in
+  // row order (they are distinct as they come: rows are sorted by partition, predicate, subject) and the
+  // object entries sorted and de-duplicated. Each has its own per-partition bases (n_partitions + 1).
+  DevBuf<uint64_t> vpi_s, vpi_o;
+  std::vector<uint64_t> vpi_s_base, vpi_o_base;
   int vpi_bits_term = 0, vpi_bits_pred = 0;
   // sorted distinct input triples packed as (pidx, s, o) plus what is needed to unpack them
   DevBuf<uint64_t> uniq;
