@@ -251,6 +251,41 @@ __device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos
   return 4 * i + sh + k;
 }
 
+// Stages [tile0 - TK_PRE, tile0 + TK_WIN) of the text into `win`, clipped to the text; bytes outside it and
+// the four padding words after the window read as '\n'. Ends with a block barrier.
+// LDS-DMA: every wave-instruction moves 64 x 16 contiguous bytes straight into the window (no VGPR staging,
+// all copies of a wave in flight at once). Only the spans touching the ends of the text are assembled by hand.
+__device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __restrict__ text, uint64_t n, uint64_t tile0) {
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  constexpr uint32_t kStageBytes = TK_PRE + TK_WIN;
+#pragma unroll
+  for (uint32_t it = 0; it < (kStageBytes + TK_THREADS * 16 - 1) / (TK_THREADS * 16); ++it) {
+    const uint32_t wave_c = it * (TK_THREADS * 16) + wv * 1024;  // window offset of this wave's 1 KiB span
+    if (wave_c >= kStageBytes) continue;
+    const int64_t wave_g = (int64_t)tile0 - TK_PRE + wave_c;
+    const uint32_t c = wave_c + ln * 16;
+    if (wave_g >= 0 && (uint64_t)wave_g + 1024 <= n && wave_c + 1024 <= kStageBytes) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(text + wave_g + ln * 16),
+                                       (__attribute__((address_space(3))) void*)&win[wave_c >> 2], 16, 0, 0);
+    } else if (c < kStageBytes) {
+      const int64_t g = wave_g + ln * 16;
+      uint32_t w[4];
+      for (int j = 0; j < 4; ++j) {
+        w[j] = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int64_t gi = g + j * 4 + k;
+          const uint8_t ch = (gi >= 0 && (uint64_t)gi < n) ? text[gi] : (uint8_t)'\n';
+          w[j] |= (uint32_t)ch << (8 * k);
+        }
+      }
+      *reinterpret_cast<uint4*>(&win[c >> 2]) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  if (threadIdx.x < 4) win[(TK_PRE + TK_WIN) / 4 + threadIdx.x] = 0x0A0A0A0Au;
+  __builtin_amdgcn_s_waitcnt(0);  // the DMA copies count on vmcnt
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(TK_THREADS)
 k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask,
            const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash, uint64_t n_rec,
@@ -265,39 +300,7 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
   // stage [tile0 - TK_PRE, tile0 + TK_WIN) clipped to the text; bytes outside read as '\n'
   const uint64_t avail = n - tile0;
   const uint32_t win_bytes = avail < (uint64_t)TK_WIN ? (uint32_t)avail : (uint32_t)TK_WIN;
-  // LDS-DMA: every wave-instruction moves 64 x 16 contiguous bytes straight into the window (no VGPR
-  // staging, all copies of a wave in flight at once). Only the spans touching the ends of the text are
-  // assembled by hand.
-  {
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    constexpr uint32_t kStageBytes = TK_PRE + TK_WIN;
-#pragma unroll
-    for (uint32_t it = 0; it < (kStageBytes + TK_THREADS * 16 - 1) / (TK_THREADS * 16); ++it) {
-      const uint32_t wave_c = it * (TK_THREADS * 16) + wv * 1024;  // window offset of this wave's 1 KiB span
-      if (wave_c >= kStageBytes) continue;
-      const int64_t wave_g = (int64_t)tile0 - TK_PRE + wave_c;
-      const uint32_t c = wave_c + ln * 16;
-      if (wave_g >= 0 && (uint64_t)wave_g + 1024 <= n && wave_c + 1024 <= kStageBytes) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(text + wave_g + ln * 16),
-                                         (__attribute__((address_space(3))) void*)&win[wave_c >> 2], 16, 0, 0);
-      } else if (c < kStageBytes) {
-        const int64_t g = wave_g + ln * 16;
-        uint32_t w[4];
-        for (int j = 0; j < 4; ++j) {
-          w[j] = 0;
-          for (int k = 0; k < 4; ++k) {
-            const int64_t gi = g + j * 4 + k;
-            const uint8_t ch = (gi >= 0 && (uint64_t)gi < n) ? text[gi] : (uint8_t)'\n';
-            w[j] |= (uint32_t)ch << (8 * k);
-          }
-        }
-        *reinterpret_cast<uint4*>(&win[c >> 2]) = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-    }
-  }
-  if (threadIdx.x < 4) win[(TK_PRE + TK_WIN) / 4 + threadIdx.x] = 0x0A0A0A0Au;
-  __builtin_amdgcn_s_waitcnt(0);  // the DMA copies count on vmcnt
-  __syncthreads();
+  stage_window(win, text, n, tile0);
   if (exp_mode == 2) {  // timing experiment: staging only
     for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
       const uint64_t r = (uint64_t)first_rec + lr;
@@ -506,50 +509,90 @@ k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ 
 
 // first[i] = 1 when occurrence i is its slot's representative; any occurrence whose bytes differ from
 // the representative's proves a 64-bit collision between different strings.
-__global__ void __launch_bounds__(256)
-k_dict_verify(const uint8_t* __restrict__ text, const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot,
-              uint64_t n_occ, const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
-  // Threads walk the occurrences record by record (s, p, o of record 0, then of record 1, ...) although
-  // the arrays are field-major: that way a wave re-reads one contiguous stretch of the text once, instead
-  // of every field pass pulling every cache line of the text through HBM again.
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_occ) return;
-  const uint64_t n_rec = n_occ / 3;
-  const uint64_t i = (t % 3) * n_rec + t / 3;
-  const uint64_t mine = t_rep[i], r = ht[t_slot[i]].val;
-  if (mine == r) { first[i] = 1; return; }
-  first[i] = 0;
-  const uint64_t lm = mine & ((1ull << kRepLenBits) - 1), lr = r & ((1ull << kRepLenBits) - 1);
-  uint64_t diff = lm ^ lr;
-  if (!diff) {
-    const uint8_t* a = text + (mine >> kRepLenBits);
-    const uint8_t* b = text + (r >> kRepLenBits);
-    // No early exit (a mismatch practically never happens, and independent loads pipeline) and no byte
-    // tail: the last load of each width overlaps the one before it. gfx950 serves unaligned wide loads.
-    auto d16 = [&](uint64_t off) {
-      uint4 x, y;
-      __builtin_memcpy(&x, a + off, 16);
-      __builtin_memcpy(&y, b + off, 16);
-      diff |= (uint64_t)((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w));
-    };
-    if (lm >= 16) {
-      for (uint64_t j = 0; j + 16 < lm; j += 16) d16(j);
-      d16(lm - 16);
-    } else if (lm >= 8) {
-      uint64_t x, y, x2, y2;
-      __builtin_memcpy(&x, a, 8); __builtin_memcpy(&y, b, 8);
-      __builtin_memcpy(&x2, a + lm - 8, 8); __builtin_memcpy(&y2, b + lm - 8, 8);
-      diff |= (x ^ y) | (x2 ^ y2);
-    } else if (lm >= 4) {
-      uint32_t x, y, x2, y2;
-      __builtin_memcpy(&x, a, 4); __builtin_memcpy(&y, b, 4);
-      __builtin_memcpy(&x2, a + lm - 4, 4); __builtin_memcpy(&y2, b + lm - 4, 4);
-      diff |= (uint64_t)((x ^ y) | (x2 ^ y2));
-    } else {
-      for (uint64_t j = 0; j < lm; ++j) diff |= (uint64_t)(a[j] ^ b[j]);
+// The kernel walks the text the way the tokeniser does: one block per tile, the tile staged into LDS with
+// wide coalesced copies, one thread per record. An occurrence's own bytes are then read from LDS a word
+// at a time; only the representative's bytes (somewhere earlier in the text, mostly cache-resident for
+// frequent terms) come from global memory. Reading the own bytes lane by lane from global memory instead
+// costs more than the rest of the kernel together.
+__device__ __forceinline__ uint64_t diff_global(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t len) {
+  uint64_t diff = 0;
+  uint64_t j = 0;
+  for (; j + 8 <= len; j += 8) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, a + j, 8); __builtin_memcpy(&y, b + j, 8);
+    diff |= x ^ y;
+  }
+  for (; j < len; ++j) diff |= (uint64_t)(a[j] ^ b[j]);
+  return diff;
+}
+
+__global__ void __launch_bounds__(TK_THREADS)
+k_dict_verify(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_first, const uint64_t* __restrict__ t_rep,
+              const uint32_t* __restrict__ t_slot, uint64_t n_rec, const DictSlot* __restrict__ ht, uint8_t* __restrict__ first,
+              uint32_t* __restrict__ collision) {
+  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 4];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
+  const uint32_t first_rec = tile_first[blockIdx.x];
+  const uint32_t n_here = tile_first[blockIdx.x + 1] - first_rec;
+  if (n_here == 0) return;  // block-uniform
+  stage_window(win, text, n, tile0);
+  const uint64_t avail = n - tile0;
+  const uint64_t win_end = tile0 + (avail < (uint64_t)TK_WIN ? avail : (uint64_t)TK_WIN);  // text offset one past the window
+  const uint64_t len_mask = (1ull << kRepLenBits) - 1;
+  bool bad = false;
+  for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
+    const uint64_t rec = (uint64_t)first_rec + lr;
+    uint64_t mine[3], rep[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mine[k] = t_rep[k * n_rec + rec];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rep[k] = ht[t_slot[k * n_rec + rec]].val;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const bool is_first = mine[k] == rep[k];
+      first[k * n_rec + rec] = is_first;
+      if (is_first) continue;
+      const uint64_t len = mine[k] & len_mask;
+      if (len != (rep[k] & len_mask)) { bad = true; continue; }
+      const uint64_t own = mine[k] >> kRepLenBits;
+      const uint8_t* b = text + (rep[k] >> kRepLenBits);
+      if (own < tile0 || own + len > win_end) {  // a record the tokeniser took out of the window as well
+        bad |= diff_global(text + own, b, len) != 0;
+        continue;
+      }
+      const uint32_t pos = (uint32_t)(own - tile0) + TK_PRE;
+      uint32_t diff = 0;
+      uint32_t i = pos >> 2;
+      const uint32_t sh = pos & 3;
+      uint32_t lo = win[i];
+      uint32_t j = 0;
+      for (; j + 16 <= len; j += 16) {  // 16 representative bytes per global load against 5 LDS words
+        uint4 y;
+        __builtin_memcpy(&y, b + j, 16);
+        const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
+        diff |= (__builtin_amdgcn_alignbyte(w1, lo, sh) ^ y.x) | (__builtin_amdgcn_alignbyte(w2, w1, sh) ^ y.y) |
+                (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ y.z) | (__builtin_amdgcn_alignbyte(w4, w3, sh) ^ y.w);
+        lo = w4;
+        i += 4;
+      }
+      for (; j + 4 <= len; j += 4) {
+        uint32_t y;
+        __builtin_memcpy(&y, b + j, 4);
+        const uint32_t w1 = win[i + 1];
+        diff |= __builtin_amdgcn_alignbyte(w1, lo, sh) ^ y;
+        lo = w1;
+        ++i;
+      }
+      if (j < len) {
+        const uint32_t x = __builtin_amdgcn_alignbyte(win[i + 1], lo, sh);
+        uint32_t y = 0;
+        for (uint32_t t = 0; j + t < len; ++t) y |= (uint32_t)b[j + t] << (8 * t);
+        diff |= (x ^ y) & ((1u << (8 * (uint32_t)(len - j))) - 1u);
+      }
+      bad |= diff != 0;
     }
   }
-  if (diff) *collision = 1;
+  if (bad) *collision = 1;
 }
 
 __global__ void __launch_bounds__(256)
@@ -594,27 +637,27 @@ k_merge_flags(const uint8_t* __restrict__ is_vertex, const uint8_t* __restrict__
     flags[t] = (is_vertex[t] ? kFlagVertex : 0) | (has_edge[t] ? kFlagEdge : 0) | (is_literal[t] ? kFlagLiteral : 0);
 }
 
-// Copies term bytes from the input text into the id-ordered pool: one thread per term, 16 bytes at a
-// time (unaligned wide loads and stores), the last chunk overlapping the one before instead of a byte tail.
-// Neighbouring threads write neighbouring pool ranges.
+// Copies term bytes from the input text into the id-ordered pool: four lanes per term, 16 bytes per lane and
+// step (unaligned wide loads and stores), the last chunk overlapping the one before instead of a byte tail.
+// Neighbouring lane groups write neighbouring pool ranges.
 __global__ void __launch_bounds__(256)
 k_pool_copy(const uint8_t* __restrict__ text, const uint64_t* __restrict__ term_src, const uint64_t* __restrict__ pool_off,
             uint64_t n_terms, uint8_t* __restrict__ pool) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = g >> 2;
+  const uint32_t sub = (uint32_t)g & 3;
   if (t >= n_terms) return;
   const uint64_t b = pool_off[t], len = pool_off[t + 1] - b;
   const uint8_t* src = text + term_src[t];
   uint8_t* dst = pool + b;
   if (len >= 16) {
-    for (uint64_t j = 0; j + 16 < len; j += 16) {
+    for (uint64_t j = 16ull * sub; j < len; j += 64) {
+      const uint64_t at = j + 16 <= len ? j : len - 16;
       uint4 v;
-      __builtin_memcpy(&v, src + j, 16);
-      __builtin_memcpy(dst + j, &v, 16);
+      __builtin_memcpy(&v, src + at, 16);
+      __builtin_memcpy(dst + at, &v, 16);
     }
-    uint4 v;
-    __builtin_memcpy(&v, src + len - 16, 16);
-    __builtin_memcpy(dst + len - 16, &v, 16);
-  } else {
+  } else if (sub == 0) {
     for (uint64_t j = 0; j < len; ++j) dst[j] = src[j];
   }
 }
@@ -1117,7 +1160,6 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   // 4 slots per record can never overflow (at most 3 distinct terms per record).
   uint64_t cap = 1024;
   while (cap < n_rec + n_rec / 2) cap <<= 1;
-  if (getenv("DX_CAP_SHIFT")) cap >>= atoi(getenv("DX_CAP_SHIFT"));
   DevBuf<DictSlot> ht(pool, cap);
   DevBuf<uint8_t> first(pool, n_occ);
   DevBuf<uint32_t> first_scan(pool, n_occ);
@@ -1141,7 +1183,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipMemsetAsync(coll.p, 0, 8, s));
     if (n_occ) hipLaunchKernelGGL(k_dict_insert, dim3(blocks(n_occ)), dim3(256), 0, s, t_hash.p, t_rep.p, n_occ, ht.p, cap - 1, t_slot.p, coll.p + 1);
     DX_HIP(hipEventRecord(e2, s));
-    if (n_occ) hipLaunchKernelGGL(k_dict_verify, dim3(blocks(n_occ)), dim3(256), 0, s, text, t_rep.p, t_slot.p, n_occ, ht.p, first.p, coll.p);
+    if (n_occ) hipLaunchKernelGGL(k_dict_verify, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, tile_counts.p, t_rep.p, t_slot.p, (uint64_t)n_rec,
+                                  ht.p, first.p, coll.p);
     DX_HIP(hipEventRecord(e3, s));
     exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
     unsigned long long h_err = ~0ull;
@@ -1206,7 +1249,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemcpyAsync(&pool_bytes, d_total64.p, 8, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
   d.pool = DevBuf<uint8_t>(pool, pool_bytes + 16);
-  if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks((uint64_t)n_terms)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
+  if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * n_terms)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
                                   (uint64_t)n_terms, d.pool.p);
   tm.mark();
   t_rep.reset(); term_src.reset(); term_len.reset();
