@@ -9,9 +9,10 @@ namespace dx {
 constexpr int kWave = 64;
 
 // ---- term hash ------------------------------------------------------------------------------
-// Two murmur-style 32-bit lanes fed with the term's bytes four at a time (little-endian words
-// counted from the term's first byte; a final partial word is zero-padded), finalised together with
-// the length into one 64-bit word. The same code runs on the host (query constants, class-index
+// A 64-bit state of two 32-bit halves fed with the term's bytes four at a time (little-endian words
+// counted from the term's first byte; a final partial word is zero-padded): a murmur-style step on one
+// half, folded into the other, the halves swapping roles every word; finalised together with the length
+// into one 64-bit word. The same code runs on the host (query constants, class-index
 // entries) and on the device (tokeniser, lookups). A hash is only a bucket choice: every dictionary
 // hit is confirmed by a full byte compare, and a true 64-bit collision between different strings
 // makes the build restart with another seed.
@@ -21,11 +22,13 @@ struct TermHash {
       : a(0x9747B28Cu ^ (uint32_t)seed), b(0x85EBCA6Bu ^ (uint32_t)(seed >> 32)) {}
   static __host__ __device__ inline uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
   __host__ __device__ inline void add_word(uint32_t k) {
-    // one multiply per lane and word (v_mul_lo_u32 is quarter rate); x * 5 + c is a shift-add
-    a = rotl(a ^ rotl(k * 0xCC9E2D51u, 15), 13);
-    a = (a << 2) + a + 0xE6546B64u;
-    b = rotl(b ^ rotl(k * 0x85EBCA77u, 13), 17);
-    b = (b << 2) + b + 0x561CCD1Bu;
+    // One multiply per word (v_mul_lo_u32 is quarter rate); x * 5 + c is a shift-add. The step is a
+    // bijection of the 64-bit state for a fixed word and of the word for a fixed state, so two strings that
+    // differ in one word never meet again, and the word reaches both halves of the state at once.
+    uint32_t x = rotl(a ^ (k * 0xCC9E2D51u), 15);
+    x = (x << 2) + x + 0xE6546B64u;
+    a = b ^ x;
+    b = x;
   }
   __host__ __device__ inline uint64_t finish(uint32_t len) const {
     uint64_t h = ((uint64_t)a << 32) | (uint64_t)(b ^ len);

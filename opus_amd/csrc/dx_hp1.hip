@@ -211,15 +211,15 @@ __device__ __noinline__ void tokenise_record_slow(const uint8_t* __restrict__ te
   out.kind = kd;
 }
 
-// Fast path: one block stages a 32 KiB tile (+ 8 KiB so that lines starting near its end are whole)
+// Fast path: one block stages a 32 KiB tile (+ 2 KiB so that lines starting near its end are whole)
 // into LDS with coalesced 16-byte loads, finds the record starts there, and each thread tokenises
 // records out of LDS four bytes at a time (unaligned words via v_alignbyte, delimiter search by SWAR,
 // hashing fused into the scan of subject and predicate).
 constexpr int TK_THREADS = 256;
-constexpr int TK_OVER = 6144;
+constexpr int TK_OVER = 2048;
 constexpr int TK_WIN = LS_TILE + TK_OVER;      // bytes staged per block
 constexpr int TK_PRE = 16;                     // bytes staged before the tile (only the last one is looked at)
-constexpr int TK_MAXREC = LS_TILE / 5 + 2;     // "a b \n" is the shortest record the reference accepts
+constexpr int TK_STARTS = 1024;                // record starts listed per round (a tile of ordinary lines has ~200)
 
 __device__ __forceinline__ uint32_t lds_word(const uint32_t* win, uint32_t pos) {  // 4 bytes at any byte offset
   const uint32_t i = pos >> 2;
@@ -231,28 +231,46 @@ __device__ __forceinline__ uint8_t lds_byte(const uint32_t* win, uint32_t pos) {
 
 // Scans a subject/predicate field starting at pos and feeds its bytes to h; returns the position of the
 // byte that ended it (the first byte <= 0x20). The loop has one exit and no bound of its own: the staged
-// window is followed by line-feed padding, so it stops at the latest there. One LDS word is read per
-// four bytes: the upper word of each unaligned read is carried over as the lower word of the next.
+// window is followed by line-feed padding, so it stops at the latest there. Four LDS words are requested
+// per round (one wait for four reads: the loop is bound by LDS latency, not by instruction issue); the
+// upper word of each unaligned read is carried over as the lower word of the next.
 __device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos, TermHash& h) {
   uint32_t i = pos >> 2;
   const uint32_t sh = pos & 3;
-  uint32_t lo = win[i], v, m;
+  uint32_t lo = win[i];
+  uint32_t v0, v1, v2, v3, m0, m1, m2, m3;
   for (;;) {
-    const uint32_t hi = win[i + 1];
-    v = __builtin_amdgcn_alignbyte(hi, lo, sh);
-    m = le20_mask(v);
-    if (m) break;
-    h.add_word(v);
-    ++i;
-    lo = hi;
+    const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
+    v0 = __builtin_amdgcn_alignbyte(w1, lo, sh);
+    v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    v2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+    v3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    m0 = le20_mask(v0); m1 = le20_mask(v1); m2 = le20_mask(v2); m3 = le20_mask(v3);
+    if (m0 | m1 | m2 | m3) break;
+    h.add_word(v0); h.add_word(v1); h.add_word(v2); h.add_word(v3);
+    i += 4;
+    lo = w4;
+  }
+  uint32_t v = v0, m = m0, base = 0;
+  if (!m0) {
+    h.add_word(v0);
+    v = v1; m = m1; base = 1;
+    if (!m1) {
+      h.add_word(v1);
+      v = v2; m = m2; base = 2;
+      if (!m2) {
+        h.add_word(v2);
+        v = v3; m = m3; base = 3;
+      }
+    }
   }
   const uint32_t k = (uint32_t)(__ffs((int)m) - 1) >> 3;
   if (k) h.add_word(v & ((1u << (8 * k)) - 1u));
-  return 4 * i + sh + k;
+  return 4 * (i + base) + sh + k;
 }
 
 // Stages [tile0 - TK_PRE, tile0 + TK_WIN) of the text into `win`, clipped to the text; bytes outside it and
-// the four padding words after the window read as '\n'. Ends with a block barrier.
+// the eight padding words after the window read as '\n'. Ends with a block barrier.
 // LDS-DMA: every wave-instruction moves 64 x 16 contiguous bytes straight into the window (no VGPR staging,
 // all copies of a wave in flight at once). Only the spans touching the ends of the text are assembled by hand.
 __device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __restrict__ text, uint64_t n, uint64_t tile0) {
@@ -281,7 +299,7 @@ __device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __res
       *reinterpret_cast<uint4*>(&win[c >> 2]) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
-  if (threadIdx.x < 4) win[(TK_PRE + TK_WIN) / 4 + threadIdx.x] = 0x0A0A0A0Au;
+  if (threadIdx.x < 8) win[(TK_PRE + TK_WIN) / 4 + threadIdx.x] = 0x0A0A0A0Au;
   __builtin_amdgcn_s_waitcnt(0);  // the DMA copies count on vmcnt
   __syncthreads();
 }
@@ -289,9 +307,9 @@ __device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __res
 __global__ void __launch_bounds__(TK_THREADS)
 k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask,
            const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash, uint64_t n_rec,
-           uint64_t* __restrict__ t_rep /*[field][record]: (offset << 24) | length*/, uint64_t* __restrict__ t_hash /*[field][record]*/, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err, int exp_mode) {
-  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 4];
-  __shared__ uint16_t starts[TK_MAXREC];
+           uint64_t* __restrict__ t_rep /*[field][record]: (offset << 24) | length*/, uint64_t* __restrict__ t_hash /*[field][record]*/, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 8];
+  __shared__ uint16_t starts[TK_STARTS];
   __shared__ uint32_t scan_lds[8];
   const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
   const uint32_t first_rec = tile_first[blockIdx.x];
@@ -301,31 +319,20 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
   const uint64_t avail = n - tile0;
   const uint32_t win_bytes = avail < (uint64_t)TK_WIN ? (uint32_t)avail : (uint32_t)TK_WIN;
   stage_window(win, text, n, tile0);
-  if (exp_mode == 2) {  // timing experiment: staging only
-    for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
-      const uint64_t r = (uint64_t)first_rec + lr;
-      for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_hash[k * n_rec + r] = 1; }
-      kind[r] = (uint8_t)(win[lr & 1023] >> 31);
-    }
-    return;
-  }
   // record starts of this tile, in order. Positions are window offsets (tile byte i is at TK_PRE + i).
+  const uint32_t seg = TK_PRE + threadIdx.x * LS_PER_THREAD;  // thread t owns starts at [seg, seg + 128)
+  uint32_t smask[4] = {0, 0, 0, 0};  // bit i of the 128: a record starts at byte i of this thread's segment
+  uint32_t at0;
   {
-    const uint32_t seg = TK_PRE + threadIdx.x * LS_PER_THREAD;  // thread t owns starts at [seg, seg + 128)
     const uint32_t seg_tile = threadIdx.x * LS_PER_THREAD;
-    uint32_t cnt = 0;
-    uint32_t smask[4] = {0, 0, 0, 0};  // bit i of the 128: a record starts at byte i of this thread's segment
     if (seg_tile < win_bytes) {
       const uint4 mv = *reinterpret_cast<const uint4*>(chunk_mask + ((tile0 + seg_tile) >> 4));  // 8 chunk masks = 128 bits
       smask[0] = mv.x; smask[1] = mv.y; smask[2] = mv.z; smask[3] = mv.w;
     }
-    cnt = __popc(smask[0]) + __popc(smask[1]) + __popc(smask[2]) + __popc(smask[3]);
+    const uint32_t cnt = __popc(smask[0]) + __popc(smask[1]) + __popc(smask[2]) + __popc(smask[3]);
     uint32_t total;
-    uint32_t at = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);
-    // Lines too short to hold three fields can be denser than the lists allow for. They are errors in
-    // any case: flag the tile, give its records harmless outputs and stop.
-    const bool dense = __syncthreads_or(total > (uint32_t)TK_MAXREC || total != n_here);
-    if (dense) {
+    at0 = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);
+    if (__syncthreads_or(total != n_here)) {  // the masks and the counts come from one kernel: cannot differ
       if (threadIdx.x == 0) atomicMin(err, (unsigned long long)tile0);
       for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
         const uint64_t r = (uint64_t)first_rec + lr;
@@ -334,29 +341,29 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       }
       return;
     }
+  }
+  const uint32_t limit = TK_PRE + win_bytes;           // one past the last staged text byte
+  const bool window_is_eof = tile0 + win_bytes >= n;   // staged window reaches the end of the text
+  // The starts are listed TK_STARTS at a time; only a tile of very short lines needs a second round.
+  for (uint32_t base = 0; base < n_here; base += TK_STARTS) {  // block-uniform
+  if (base) __syncthreads();
+  {
+    uint32_t at = at0 - base;  // wraps below the round's range and fails the bound check there
 #pragma unroll
     for (int wd = 0; wd < 4; ++wd) {
       uint32_t m = smask[wd];
       while (m) {
         const int bit = __ffs((int)m) - 1;
         m &= m - 1;
-        starts[at++] = (uint16_t)(seg + wd * 32 + bit);
+        if (at < (uint32_t)TK_STARTS) starts[at] = (uint16_t)(seg + wd * 32 + bit);
+        ++at;
       }
     }
   }
   __syncthreads();
-  if (exp_mode == 1) {  // timing experiment: staging and start detection only, harmless outputs
-    for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
-      const uint64_t r = (uint64_t)first_rec + lr;
-      for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_hash[k * n_rec + r] = 1; }
-      kind[r] = 0;
-    }
-    return;
-  }
-  const uint32_t limit = TK_PRE + win_bytes;           // one past the last staged text byte
-  const bool window_is_eof = tile0 + win_bytes >= n;   // staged window reaches the end of the text
-  for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
-    const uint32_t p0 = starts[lr];
+  const uint32_t round_end = n_here - base < (uint32_t)TK_STARTS ? n_here : base + TK_STARTS;
+  for (uint32_t lr = base + threadIdx.x; lr < round_end; lr += TK_THREADS) {
+    const uint32_t p0 = starts[lr - base];
     const uint64_t gstart = tile0 + (p0 - TK_PRE);
     RecordOut out;
     out.bad = false;
@@ -385,21 +392,27 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       odd |= (lds_byte(win, p) <= 0x20) & !is_eol(lds_byte(win, p));  // an empty object is fine
     }
     b[2] = p;
-    {  // end of line: first LF / CR at or after the object's first byte
+    {  // end of line: first LF / CR at or after the object's first byte, four words per round
       uint32_t i = p >> 2;
       const uint32_t sh = p & 3;
-      uint32_t lo = win[i], v, m;
+      uint32_t lo = win[i];
+      uint32_t v0, v1, v2, v3, m0, m1, m2, m3;
       for (;;) {
-        const uint32_t hi = win[i + 1];
-        v = __builtin_amdgcn_alignbyte(hi, lo, sh);
-        m = eol_candidates(v);
-        if (m) break;
-        ++i;
-        lo = hi;
+        const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
+        v0 = __builtin_amdgcn_alignbyte(w1, lo, sh);
+        v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        v2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        v3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+        m0 = eol_candidates(v0); m1 = eol_candidates(v1); m2 = eol_candidates(v2); m3 = eol_candidates(v3);
+        if (m0 | m1 | m2 | m3) break;
+        i += 4;
+        lo = w4;
       }
+      uint32_t v = v0, m = m0, base = 0;
+      if (!m0) { v = v1; m = m1; base = 1; if (!m1) { v = v2; m = m2; base = 2; if (!m2) { v = v3; m = m3; base = 3; } } }
       const uint32_t k = (uint32_t)(__ffs((int)m) - 1) >> 3;
       odd |= !is_eol((uint8_t)(v >> (8 * k)));  // a VT / FF inside the object
-      e[2] = 4 * i + sh + k;
+      e[2] = 4 * (i + base) + sh + k;
     }
     odd |= (e[2] > limit) | ((e[2] == limit) & !window_is_eof);  // the line runs past the staged window
     if (!odd) {
@@ -416,10 +429,18 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     if (odd) {
       tokenise_record_slow(text, n, gstart, seed, out);
     } else {
-      {  // object hash
+      {  // object hash, four words per round
         uint32_t q = b[2], i = q >> 2;
         const uint32_t sh = q & 3;
         uint32_t lo = win[i];
+        for (; q + 16 <= e[2]; q += 16, i += 4) {
+          const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
+          ho.add_word(__builtin_amdgcn_alignbyte(w1, lo, sh));
+          ho.add_word(__builtin_amdgcn_alignbyte(w2, w1, sh));
+          ho.add_word(__builtin_amdgcn_alignbyte(w3, w2, sh));
+          ho.add_word(__builtin_amdgcn_alignbyte(w4, w3, sh));
+          lo = w4;
+        }
         for (; q + 4 <= e[2]; q += 4, ++i) {
           const uint32_t hi = win[i + 1];
           ho.add_word(__builtin_amdgcn_alignbyte(hi, lo, sh));
@@ -452,6 +473,7 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     }
     for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = out.rep[k]; t_hash[k * n_rec + r] = out.hash[k]; }  // field-major: coalesced
     kind[r] = out.kind;
+  }
   }
 }
 
@@ -530,7 +552,7 @@ __global__ void __launch_bounds__(TK_THREADS)
 k_dict_verify(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_first, const uint64_t* __restrict__ t_rep,
               const uint32_t* __restrict__ t_slot, uint64_t n_rec, const DictSlot* __restrict__ ht, uint8_t* __restrict__ first,
               uint32_t* __restrict__ collision) {
-  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 8];
   const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
   const uint32_t first_rec = tile_first[blockIdx.x];
   const uint32_t n_here = tile_first[blockIdx.x + 1] - first_rec;
@@ -1176,7 +1198,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     if (n_rec && !tokenised)
       hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed,
                          hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec, t_rep.p,
-                         t_hash.p, kind.p, err.p, getenv("DX_TOK_EXP") ? atoi(getenv("DX_TOK_EXP")) : 0);
+                         t_hash.p, kind.p, err.p);
     DX_HIP(hipEventRecord(e1, s));
     // ---- 3. dictionary
     hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
