@@ -212,15 +212,20 @@ def main():
         # a hipEvent pair each (tokenise+hash, dictionary insert, dictionary verify). Algorithmic bytes per
         # launch: what the kernel has to read and write once.
         n_rec, n_occ = st.n_triples, 3 * st.n_triples
-        term_bytes = max(0, n_bytes - 5 * n_rec)                 # text minus separators and " .\n"
-        repeat_share = 1.0 - st.n_terms / max(1, n_occ)          # occurrences that are not a term's first
+        import ctypes
+        pool_bytes = ctypes.c_uint64(0)                          # every distinct term once
+        all_ids = np.arange(st.n_terms, dtype=np.int64)
+        eng._check(eng.lib.dx_terms_bytes(eng.ctx, all_ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), all_ids.size,
+                                          ctypes.byref(pool_bytes)))
         kernels = {
             "k_tokenise (text -> 3 term spans + 64-bit hashes per record)":
                 (stage_avg["tokenise_hash"], n_bytes + 49 * n_rec),
             "k_ht_clear + k_dict_insert (claim a 16-byte slot per term, keep the first occurrence)":
                 (stage_avg["dict_insert_kernel"], 36 * n_occ),
+            # the text once (every occurrence's own bytes), every distinct term's first bytes once, and per
+            # occurrence the span word (8), the slot index (4), the slot's representative (8), the flag (1)
             "k_dict_verify (byte-compare every repeated occurrence with its term's first)":
-                (stage_avg["dict_verify_kernel"], 21 * n_occ + 2 * repeat_share * term_bytes),
+                (stage_avg["dict_verify_kernel"], n_bytes + pool_bytes.value + 21 * n_occ),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
