@@ -152,6 +152,39 @@ const char* dx_result_plan(dx_result* r);
 double dx_result_device_ms(dx_result* r);
 void dx_result_free(dx_result* r);
 
+/* ---- query processor on several GPUs ------------------------------------------------------------------
+ * One process and one dx_ctx per GPU. Every rank opens the same layout (one dictionary, so term ids agree),
+ * loads the tables of the first-level partitions it owns with dx_load_table and names the others with
+ * dx_declare_remote_table. dx_query is then collective: every rank passes the same statement; scans and
+ * filters run where the table lives, and before each join both inputs are redistributed by a hash of the
+ * join key. This is the exchange Spark plans inside spark.sqlContext.sql (QueryProcessor.scala:187,192,
+ * spark.sql.shuffle.partitions :124,139), with the GPUs of the node in the place of its shuffle partitions.
+ * The library does not open connections itself: the host hands it three collectives (over RCCL in
+ * production, anything else in tests). Buffers passed to `exchange` are device memory of this rank's GPU;
+ * the call returns when recv_dev is complete. Counts are in elements, grouped by peer in rank order. */
+typedef struct dx_comm {
+  int rank, world;
+  void* user;
+  /* recv[p] = the value peer p passed as send[rank] */
+  int (*exchange_counts)(void* user, const uint64_t* send, uint64_t* recv);
+  /* all-to-all with per-peer counts of elements of elem_bytes bytes */
+  int (*exchange)(void* user, const void* send_dev, const uint64_t* send_counts, void* recv_dev, const uint64_t* recv_counts,
+                  int elem_bytes);
+  /* element-wise sum over all ranks, result on every rank */
+  int (*allreduce_sum)(void* user, uint64_t* values, int n);
+} dx_comm;
+/* comm == NULL or world == 1 returns the context to single-GPU execution. */
+int dx_set_comm(dx_ctx* ctx, const dx_comm* comm);
+/* A table of the `partitions` line that another rank holds (same key syntax as dx_load_table). */
+int dx_declare_remote_table(dx_ctx* ctx, const char* partition_key);
+/* Rows, distinct subjects and distinct objects of a table: read them where it is loaded, sum or share them
+ * between the ranks, and set them everywhere, so that every rank derives the same join order. */
+int dx_table_stats(dx_ctx* ctx, const char* partition_key, uint64_t out[3]);
+int dx_set_table_stats(dx_ctx* ctx, const char* partition_key, const uint64_t in[3]);
+/* With a communicator set, dx_result_count is the count over all ranks and dx_result_fetch_ids returns this
+ * rank's share of the bindings: dx_result_local_rows of them (unsorted: the caller merges the shares). */
+uint64_t dx_result_local_rows(dx_result* r);
+
 #ifdef __cplusplus
 }
 #endif

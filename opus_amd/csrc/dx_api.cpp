@@ -653,6 +653,48 @@ int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
   });
 }
 
+int dx_set_comm(dx_ctx* ctx, const dx_comm* comm) {
+  return guard(ctx, [&] {
+    if (!comm || comm->world <= 1) { ctx->comm = dx_comm{0, 1, nullptr, nullptr, nullptr, nullptr}; return; }
+    if (comm->rank < 0 || comm->rank >= comm->world || !comm->exchange_counts || !comm->exchange || !comm->allreduce_sum)
+      throw DxError(DX_E_INVAL, "dx_set_comm: rank out of range or a collective is missing");
+    if (comm->world > 64) throw DxError(DX_E_RANGE, "dx_set_comm: more than 64 ranks");
+    ctx->comm = *comm;
+  });
+}
+
+int dx_declare_remote_table(dx_ctx* ctx, const char* partition_key) {
+  return guard(ctx, [&] {
+    if (!partition_key) throw DxError(DX_E_INVAL, "null key");
+    const std::string key = partition_key, view = view_name(key);
+    if (ctx->catalog.count(view)) return;
+    CatalogTable t;
+    t.key = key;
+    t.view = view;
+    t.remote = true;
+    ctx->catalog.emplace(view, std::move(t));
+  });
+}
+
+int dx_table_stats(dx_ctx* ctx, const char* partition_key, uint64_t out[3]) {
+  return guard(ctx, [&] {
+    if (!partition_key || !out) throw DxError(DX_E_INVAL, "null argument");
+    auto it = ctx->catalog.find(view_name(partition_key));
+    if (it == ctx->catalog.end()) throw DxError(DX_E_NOENT, std::string("table not loaded: ") + partition_key);
+    out[0] = it->second.rows; out[1] = it->second.distinct_s; out[2] = it->second.distinct_o;
+  });
+}
+
+int dx_set_table_stats(dx_ctx* ctx, const char* partition_key, const uint64_t in[3]) {
+  return guard(ctx, [&] {
+    if (!partition_key || !in) throw DxError(DX_E_INVAL, "null argument");
+    auto it = ctx->catalog.find(view_name(partition_key));
+    if (it == ctx->catalog.end()) throw DxError(DX_E_NOENT, std::string("table neither loaded nor declared: ") + partition_key);
+    it->second.has_plan_stats = true;
+    it->second.plan_rows = in[0]; it->second.plan_distinct_s = in[1]; it->second.plan_distinct_o = in[2];
+  });
+}
+
 int dx_unload_all(dx_ctx* ctx) {
   return guard(ctx, [&] { ctx->catalog.clear(); });
 }
@@ -662,11 +704,12 @@ int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out) {
   return guard(ctx, [&] {
     if (!sql || !out) throw DxError(DX_E_INVAL, "null argument");
     if (mode != DX_QUERY_COUNT && mode != DX_QUERY_BINDINGS) throw DxError(DX_E_INVAL, "unknown query mode");
-    *out = run_query(ctx, sql, mode);
+    *out = ctx->comm.world > 1 ? run_query_sharded(ctx, sql, mode) : run_query(ctx, sql, mode);
   });
 }
 
-uint64_t dx_result_count(dx_result* r) { return r ? r->count : 0; }
+uint64_t dx_result_count(dx_result* r) { return r ? r->global_count : 0; }
+uint64_t dx_result_local_rows(dx_result* r) { return r ? r->count : 0; }
 int dx_result_columns(dx_result* r) { return r ? (int)r->names.size() : 0; }
 const char* dx_result_column_name(dx_result* r, int i) { return (r && i >= 0 && i < (int)r->names.size()) ? r->names[i].c_str() : ""; }
 double dx_result_device_ms(dx_result* r) { return r ? r->device_ms : 0; }

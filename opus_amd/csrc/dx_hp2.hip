@@ -50,6 +50,8 @@ struct ArmDev {
   int nsrc;
   int src[3];      // 0 = s, 1 = o, 2 = constant
   int src_ci[3];
+  int direct;      // the tuple's columns are stored as they are (rows received from other ranks): no filters
+  const int64_t* d[3];
 };
 
 struct ConstArgs {
@@ -95,6 +97,12 @@ k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, u
 }
 
 __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, uint32_t i, int64_t v[3]) {
+  if (a.direct) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < a.nsrc) v[k] = a.d[k][i];
+    return true;
+  }
   // columnar: the filtered column is read first, the other one only for rows that pass
   int64_t s = 0, o = 0;
   if (a.fo >= 0) { o = a.o[i]; if (o != consts[a.fo]) return false; }
@@ -253,7 +261,8 @@ struct PlanRel {
     int src[3] = {0, 0, 0}, src_ci[3] = {-1, -1, -1};
   };
   std::vector<Arm> arms;
-  uint64_t rows_upper = 0;
+  uint64_t rows_upper = 0;       // rows of the arms held here: bounds the local scan output
+  double rows_plan = 0;          // rows of the arms over all ranks: what the cost model sees
   double est = 0;                // estimated rows after the constant filters
   double dist[3] = {1, 1, 1};    // estimated distinct values per projected column
 };
@@ -359,7 +368,10 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
       r.rows_upper += it->second.rows;
       // uniform-frequency estimate from the table's row and distinct counts (gathered when it was loaded)
       const CatalogTable& t = it->second;
-      const double n = (double)t.rows, ds = (double)std::max<uint64_t>(t.distinct_s, 1), dob = (double)std::max<uint64_t>(t.distinct_o, 1);
+      const double n = (double)(t.has_plan_stats ? t.plan_rows : t.rows);
+      const double ds = (double)std::max<uint64_t>(t.has_plan_stats ? t.plan_distinct_s : t.distinct_s, 1),
+                   dob = (double)std::max<uint64_t>(t.has_plan_stats ? t.plan_distinct_o : t.distinct_o, 1);
+      r.rows_plan += n;
       double rows = n;
       if (arm.has_s) rows /= ds;
       if (arm.has_o) rows /= dob;
@@ -419,7 +431,7 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
         cur.push_back(i);
         cur_rows.push_back(nx.rows);
         // the last step of a count query is not materialised, and every step streams its table once
-        dfs(nx, cost + ((int)cur.size() == n ? 0.0 : nx.rows) + 0.05 * (double)r.rows_upper);
+        dfs(nx, cost + ((int)cur.size() == n ? 0.0 : nx.rows) + 0.05 * r.rows_plan);
         cur.pop_back();
         cur_rows.pop_back();
         used[i] = false;
@@ -624,6 +636,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       DX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
       res->device_ms = ms;
       res->count = hb->counters[nsteps - 1];
+      res->global_count = res->count;
       if (mode == DX_QUERY_BINDINGS) {
         res->has_bindings = true;
         for (size_t c = 0; c < plan.select_cls.size(); ++c) {
@@ -641,6 +654,327 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       return res;
     }
     throw DxError(DX_E_RANGE, "query did not converge on buffer sizes");
+  } catch (...) {
+    delete res;
+    throw;
+  }
+}
+
+
+// ---- several GPUs -------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kMaxWorld = 64;
+
+// dest[i] = rank that owns row i's join key; counts[p] = rows going to rank p
+struct ShuffleKeys {
+  const int64_t* k0;
+  const int64_t* k1;  // nullptr for a one-column key
+  uint32_t rows;
+  int world;
+};
+__device__ __forceinline__ uint32_t key_owner(const ShuffleKeys& k, uint32_t i) {
+  const uint64_t h = k.k1 ? hash_key2(k.k0[i], k.k1[i]) : hash_key(k.k0[i]);
+  return (uint32_t)((h >> 32) % (uint32_t)k.world);  // the join's hash table takes the low bits
+}
+__global__ void __launch_bounds__(256)
+k_shuffle_count(ShuffleKeys k, uint8_t* __restrict__ dest, unsigned long long* __restrict__ counts) {
+  __shared__ uint32_t c[kMaxWorld];
+  if (threadIdx.x < kMaxWorld) c[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < k.rows; i += gridDim.x * blockDim.x) {
+    const uint32_t d = key_owner(k, i);
+    dest[i] = (uint8_t)d;
+    atomicAdd(&c[d], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < k.world && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c[threadIdx.x]);
+}
+// Rows grouped by destination, one column at a time per row; positions come from one atomic per wave and
+// destination present in it.
+struct ShuffleCols {
+  const int64_t* in[MAXC];
+  int64_t* out[MAXC];
+  int ncols;
+};
+__global__ void __launch_bounds__(256)
+k_shuffle_scatter(ShuffleCols sc, const uint8_t* __restrict__ dest, uint32_t rows, int world, unsigned long long* __restrict__ cursor) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (rows + stride - 1) / stride;
+  for (uint32_t rd = 0; rd < rounds; ++rd) {
+    const uint32_t i = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < rows;
+    const uint32_t d = valid ? dest[i] : 0xFFFFFFFFu;
+    unsigned long long pos = 0;
+    for (int p = 0; p < world; ++p) {  // wave-uniform
+      const uint64_t b = __ballot(d == (uint32_t)p);
+      if (!b) continue;
+      const int leader = __ffsll((unsigned long long)b) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(&cursor[p], (unsigned long long)__popcll(b));
+      base = __shfl(base, leader, 64);
+      if (d == (uint32_t)p) pos = base + __popcll(b & lt);
+    }
+    if (valid)
+      for (int c = 0; c < sc.ncols; ++c) sc.out[c][pos] = sc.in[c][i];
+  }
+}
+
+struct LocalRel {  // a relation whose row count the host knows
+  std::vector<DevBuf<int64_t>> own;
+  int64_t* col[MAXC] = {};
+  int ncols = 0;
+  uint64_t rows = 0;
+};
+
+void comm_check(int rc, const char* what) {
+  if (rc != 0) throw DxError(DX_E_IO, std::string("collective failed: ") + what);
+}
+
+// Redistributes `in` so that rows with equal key columns meet on one rank (nkey == 0: every rank gets every row).
+LocalRel shuffle(dx_ctx* ctx, const LocalRel& in, int nkey, const int* key_col) {
+  const dx_comm& cm = ctx->comm;
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  const int W = cm.world;
+  std::vector<uint64_t> send(W, 0), recv(W, 0);
+  LocalRel grouped;
+  grouped.ncols = in.ncols;
+  const uint64_t copies = nkey == 0 ? (uint64_t)W : 1;
+  if (in.rows * copies >= (1ull << 32)) throw DxError(DX_E_RANGE, "shuffle of 2^32 rows or more");
+  for (int c = 0; c < in.ncols; ++c) { grouped.own.emplace_back(pool, std::max<uint64_t>(in.rows * copies, 1)); grouped.col[c] = grouped.own.back().p; }
+  if (nkey == 0) {
+    for (int p = 0; p < W; ++p) {
+      send[p] = in.rows;
+      for (int c = 0; c < in.ncols && in.rows; ++c)
+        DX_HIP(hipMemcpyAsync(grouped.col[c] + (uint64_t)p * in.rows, in.col[c], in.rows * 8, hipMemcpyDeviceToDevice, s));
+    }
+  } else if (in.rows) {
+    DevBuf<uint8_t> dest(pool, in.rows);
+    DevBuf<unsigned long long> counts(pool, 2 * kMaxWorld);
+    DX_HIP(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * 2 * kMaxWorld, s));
+    ShuffleKeys sk{in.col[key_col[0]], nkey == 2 ? in.col[key_col[1]] : nullptr, (uint32_t)in.rows, W};
+    hipLaunchKernelGGL(k_shuffle_count, dim3(scan_grid(in.rows)), dim3(256), 0, s, sk, dest.p, counts.p);
+    std::vector<unsigned long long> h(W);
+    DX_HIP(hipMemcpyAsync(h.data(), counts.p, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> cur(W);
+    unsigned long long run = 0;
+    for (int p = 0; p < W; ++p) { send[p] = h[p]; cur[p] = run; run += h[p]; }
+    DX_HIP(hipMemcpyAsync(counts.p + kMaxWorld, cur.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, s));
+    ShuffleCols sc{};
+    sc.ncols = in.ncols;
+    for (int c = 0; c < in.ncols; ++c) { sc.in[c] = in.col[c]; sc.out[c] = grouped.col[c]; }
+    hipLaunchKernelGGL(k_shuffle_scatter, dim3(scan_grid(in.rows)), dim3(256), 0, s, sc, dest.p, (uint32_t)in.rows, W, counts.p + kMaxWorld);
+  }
+  DX_HIP(hipStreamSynchronize(s));
+  DX_HIP(hipGetLastError());
+  comm_check(cm.exchange_counts(cm.user, send.data(), recv.data()), "exchange_counts");
+  LocalRel out;
+  out.ncols = in.ncols;
+  for (int p = 0; p < W; ++p) out.rows += recv[p];
+  if (out.rows >= (1ull << 32)) throw DxError(DX_E_RANGE, "shuffle of 2^32 rows or more");
+  for (int c = 0; c < in.ncols; ++c) {
+    out.own.emplace_back(pool, std::max<uint64_t>(out.rows, 1));
+    out.col[c] = out.own.back().p;
+    comm_check(cm.exchange(cm.user, grouped.col[c], send.data(), out.col[c], recv.data(), 8), "exchange");
+  }
+  return out;
+}
+
+}  // namespace
+
+// The plan of run_query, executed by all ranks together. Differences: every arm is filtered and materialised
+// where its table lives; before a join, the arm's rows and (unless it is already spread by the same
+// variables) the intermediate are redistributed by a hash of the join key; row counts are read back after
+// every step, because the exchanges need them on the host.
+dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode) {
+  const dx_comm& cm = ctx->comm;
+  if (cm.world > kMaxWorld) throw DxError(DX_E_RANGE, "more than 64 ranks");
+  const SqlQuery q = parse_sql(sql);
+  Plan plan = make_plan(ctx, q);
+  if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  const int nsteps = (int)plan.rels.size();
+  ConstArgs ca;
+  ca.n = (int)plan.const_str.size();
+  uint32_t off = 0;
+  for (int i = 0; i < ca.n; ++i) {
+    ca.off[i] = off;
+    ca.preset[i] = plan.const_preset[i];
+    if (off + plan.const_str[i].size() > (size_t)kConstBytes) throw DxError(DX_E_UNSUPPORTED, "SQL: constants exceed 2.5 KiB in total");
+    memcpy(ca.bytes + off, plan.const_str[i].data(), plan.const_str[i].size());
+    ca.hash[i] = hash_bytes((const uint8_t*)plan.const_str[i].data(), plan.const_str[i].size(), ctx->dict.seed);
+    off += (uint32_t)plan.const_str[i].size();
+  }
+  ca.off[ca.n] = off;
+  DevBuf<int64_t> consts(pool, kMaxConsts);
+  DevBuf<unsigned long long> counter(pool, 1);
+  if (ca.n)
+    hipLaunchKernelGGL(k_resolve_consts, dim3(ca.n), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
+                       ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
+  auto read_counter = [&]() {
+    unsigned long long h = 0;
+    DX_HIP(hipMemcpyAsync(&h, counter.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    DX_HIP(hipGetLastError());
+    return (uint64_t)h;
+  };
+  // filtered, projected rows of a sub-select's arms that live here
+  auto materialise = [&](const PlanRel& r) {
+    LocalRel a;
+    a.ncols = r.ncols;
+    const uint64_t cap = std::max<uint64_t>(r.rows_upper, 1);
+    RelDev out{};
+    out.ncols = r.ncols;
+    out.cap = (uint32_t)cap;
+    out.count = counter.p;
+    for (int c = 0; c < r.ncols; ++c) { a.own.emplace_back(pool, cap); a.col[c] = a.own.back().p; out.col[c] = a.col[c]; }
+    DX_HIP(hipMemsetAsync(counter.p, 0, 8, s));
+    for (const auto& arm : r.arms)
+      if (arm.t->rows) hipLaunchKernelGGL(k_scan_emit, dim3(scan_grid(arm.t->rows)), dim3(256), 0, s, arm_dev(r, arm), consts.p, out, counter.p);
+    a.rows = read_counter();
+    return a;
+  };
+  auto* res = new dx_result();
+  res->ctx = ctx;
+  res->names = plan.select_names;
+  res->virtual_terms = plan.virtual_terms;
+  try {
+    std::ostringstream explain;
+    LocalRel I;
+    std::vector<int> I_cls, I_spread;  // classes of I's columns; classes I is spread by (sorted; empty = as it fell)
+    uint64_t local_count = 0;
+    for (int k = 0; k < nsteps; ++k) {
+      const PlanRel& r = plan.rels[k];
+      const bool last = k == nsteps - 1;
+      const bool count_only = last && mode == DX_QUERY_COUNT;
+      LocalRel A = materialise(r);
+      explain << (k ? "join " : "scan ");
+      for (size_t a = 0; a < r.arms.size(); ++a)
+        explain << (a ? " UNION " : "") << r.arms[a].t->view << (r.arms[a].t->remote ? "[remote" : "[local") << ", " << r.arms[a].t->rows << " rows]";
+      if (k == 0) {
+        I = std::move(A);
+        I_cls.assign(r.cls, r.cls + r.ncols);
+        local_count = I.rows;
+        explain << " -> " << I.rows << " rows here\n";
+        continue;
+      }
+      ProbeArgs pa{};
+      pa.consts = consts.p;
+      pa.nkey = 0;
+      pa.nnew = 0;
+      std::vector<int> new_cls, key_cls;
+      for (int c = 0; c < r.ncols; ++c) {
+        int at = -1;
+        for (size_t j = 0; j < I_cls.size(); ++j)
+          if (I_cls[j] == r.cls[c]) at = (int)j;
+        if (at >= 0) {
+          if (pa.nkey < 2) { pa.key_src[pa.nkey] = c; pa.key_col[pa.nkey] = at; ++pa.nkey; key_cls.push_back(r.cls[c]); }
+          else throw DxError(DX_E_UNSUPPORTED, "SQL: join on three columns of one sub-select");
+        } else {
+          pa.new_src[pa.nnew++] = c;
+          new_cls.push_back(r.cls[c]);
+        }
+      }
+      if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
+      // both sides hash the key columns in the same order: ascending variable class
+      if (pa.nkey == 2 && key_cls[0] > key_cls[1]) {
+        std::swap(key_cls[0], key_cls[1]);
+        std::swap(pa.key_src[0], pa.key_src[1]);
+        std::swap(pa.key_col[0], pa.key_col[1]);
+      }
+      LocalRel A2 = shuffle(ctx, A, pa.nkey, pa.key_src);  // cross product: every rank gets the whole arm
+      A = LocalRel();
+      if (pa.nkey > 0 && I_spread != key_cls) {
+        LocalRel I2 = shuffle(ctx, I, pa.nkey, pa.key_col);
+        I = std::move(I2);
+        I_spread = key_cls;
+      }
+      // local join: I is the build side, the received arm rows are streamed
+      RelDev Id{};
+      Id.ncols = I.ncols;
+      Id.cap = (uint32_t)I.rows;
+      DevBuf<unsigned long long> i_count(pool, 1);
+      const unsigned long long i_rows = I.rows;
+      DX_HIP(hipMemcpyAsync(i_count.p, &i_rows, 8, hipMemcpyHostToDevice, s));
+      Id.count = i_count.p;
+      for (int c = 0; c < I.ncols; ++c) Id.col[c] = I.col[c];
+      pa.I = Id;
+      std::vector<DevBuf<uint32_t>> tmp32;
+      if (pa.nkey > 0) {
+        uint32_t hsize = 1024;
+        while (hsize < 2ull * I.rows && hsize < (1u << 31)) hsize <<= 1;
+        tmp32.emplace_back(pool, hsize);
+        uint32_t* heads = tmp32.back().p;
+        tmp32.emplace_back(pool, std::max<uint64_t>(I.rows, 1));
+        uint32_t* next = tmp32.back().p;
+        DX_HIP(hipMemsetAsync(heads, 0xFF, (size_t)hsize * 4, s));
+        BuildArgs ba{};
+        ba.I = Id; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
+        ba.heads = heads; ba.next = next; ba.hmask = hsize - 1;
+        if (I.rows) hipLaunchKernelGGL(k_build, dim3(scan_grid(I.rows)), dim3(256), 0, s, ba);
+        pa.heads = heads; pa.next = next; pa.hmask = hsize - 1;
+      }
+      ArmDev ad{};
+      ad.rows = (uint32_t)A2.rows;
+      ad.fs = ad.fo = -1;
+      ad.nsrc = r.ncols;
+      ad.direct = 1;
+      for (int c = 0; c < r.ncols; ++c) ad.d[c] = A2.col[c];
+      pa.arm = ad;
+      pa.count_only = count_only ? 1 : 0;
+      pa.out_count = counter.p;
+      LocalRel out;
+      out.ncols = I.ncols + pa.nnew;
+      uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(I.rows, A2.rows), 1);
+      for (int attempt = 0;; ++attempt) {
+        RelDev od{};
+        od.ncols = out.ncols;
+        od.count = counter.p;
+        if (!count_only) {
+          if (cap >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
+          out.own.clear();
+          for (int c = 0; c < out.ncols; ++c) { out.own.emplace_back(pool, cap); out.col[c] = out.own.back().p; od.col[c] = out.col[c]; }
+          od.cap = (uint32_t)cap;
+        }
+        pa.out = od;
+        DX_HIP(hipMemsetAsync(counter.p, 0, 8, s));
+        if (A2.rows) hipLaunchKernelGGL(k_probe, dim3(scan_grid(A2.rows)), dim3(256), 0, s, pa);
+        out.rows = read_counter();
+        if (count_only || out.rows <= cap) break;
+        if (attempt) throw DxError(DX_E_RANGE, "join output did not fit its exact size");
+        cap = out.rows;  // the counter holds the exact size: one more pass
+      }
+      local_count = out.rows;
+      explain << " -> " << out.rows << " rows here\n";
+      if (!count_only) {
+        I = std::move(out);
+        for (int c : new_cls) I_cls.push_back(c);
+      }
+    }
+    uint64_t total = local_count;
+    comm_check(cm.allreduce_sum(cm.user, &total, 1), "allreduce_sum");
+    res->count = local_count;
+    res->global_count = total;
+    if (mode == DX_QUERY_BINDINGS) {
+      res->has_bindings = true;
+      for (size_t c = 0; c < plan.select_cls.size(); ++c) {
+        int at = -1;
+        for (size_t j = 0; j < I_cls.size(); ++j)
+          if (I_cls[j] == plan.select_cls[c]) at = (int)j;
+        if (at < 0) throw DxError(DX_E_MALFORMED, "SQL: selected column is not produced by any sub-select");
+        DevBuf<int64_t> col(pool, std::max<uint64_t>(res->count, 1));
+        if (res->count) DX_HIP(hipMemcpyAsync(col.p, I.col[at], res->count * 8, hipMemcpyDeviceToDevice, s));
+        res->cols.push_back(std::move(col));
+      }
+      DX_HIP(hipStreamSynchronize(s));
+    }
+    res->plan = explain.str();
+    return res;
   } catch (...) {
     delete res;
     throw;

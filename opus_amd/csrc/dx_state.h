@@ -74,6 +74,11 @@ struct CatalogTable {
   std::string view;     // "table00001__3_E_<pred>"
   uint64_t rows = 0;
   uint64_t distinct_s = 0, distinct_o = 0;  // gathered at load time, feed the join-order estimates
+  // several GPUs: a table another rank holds has no rows here; the planner works on the numbers of the
+  // whole table, which the host sets on every rank alike
+  bool remote = false;
+  bool has_plan_stats = false;
+  uint64_t plan_rows = 0, plan_distinct_s = 0, plan_distinct_o = 0;
   // a view is the concatenation of one or more row slices (several predicates can sanitise to one name)
   struct Slice { const int64_t* s; const int64_t* o; uint64_t rows; };
   std::vector<Slice> slices;
@@ -100,11 +105,14 @@ struct dx_ctx {
   // query workspace
   dx::DevBuf<uint8_t> qws;
   hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
+  // several GPUs: collectives handed in by the host; world == 1 means single-GPU execution
+  dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct dx_result {
   dx_ctx* ctx = nullptr;
-  uint64_t count = 0;
+  uint64_t count = 0;         // rows held by this context
+  uint64_t global_count = 0;  // rows over all ranks (== count on one GPU)
   double device_ms = 0;
   bool has_bindings = false;
   std::vector<std::string> names;
@@ -122,5 +130,6 @@ void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
 void table_statistics(dx_ctx* ctx, CatalogTable& t);  // distinct subjects / objects
 // dx_hp2.hip
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
+dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode);
 extern const char* const kStageNames[12];
 }  // namespace dx

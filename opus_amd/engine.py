@@ -30,6 +30,7 @@ EXPORTS = [
     "dx_instance_graph_fetch", "dx_part_write_layout", "dx_open_dataset", "dx_load_table", "dx_unload_all",
     "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
+    "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
 ]
 
 
@@ -109,6 +110,11 @@ def load_library():
         "dx_result_plan": (c_char_p, [c_void_p]),
         "dx_result_device_ms": (c_double, [c_void_p]),
         "dx_result_free": (None, [c_void_p]),
+        "dx_set_comm": (c_int, [c_void_p, c_void_p]),
+        "dx_declare_remote_table": (c_int, [c_void_p, c_char_p]),
+        "dx_table_stats": (c_int, [c_void_p, c_char_p, u64p]),
+        "dx_set_table_stats": (c_int, [c_void_p, c_char_p, u64p]),
+        "dx_result_local_rows": (c_uint64, [c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -130,19 +136,21 @@ class QueryResult:
     def __init__(self, engine, handle):
         self._e, self._h = engine, handle
         lib = engine.lib
-        self.count = int(lib.dx_result_count(handle))
+        self.count = int(lib.dx_result_count(handle))            # over all ranks
+        self.local_rows = int(lib.dx_result_local_rows(handle))  # held by this rank (== count on one GPU)
         self.columns = [lib.dx_result_column_name(handle, i).decode() for i in range(lib.dx_result_columns(handle))]
         self.device_ms = float(lib.dx_result_device_ms(handle))
         self.plan = lib.dx_result_plan(handle).decode()
 
     def ids(self, sort=False):
         """(count, n_columns) int64 array of term ids (needs DX_QUERY_BINDINGS)."""
-        a = _i64(self.count * max(1, len(self.columns)))
+        a = _i64(self.local_rows * max(1, len(self.columns)))
         self._e._check(self._e.lib.dx_result_fetch_ids(self._h, _p(a), 1 if sort else 0))
-        return a.reshape(len(self.columns), self.count).T.copy() if self.columns else a.reshape(0, 0)
+        return a.reshape(len(self.columns), self.local_rows).T.copy() if self.columns else a.reshape(0, 0)
 
     def rows(self):
-        """Decoded bindings: sorted list of tuples of raw N-Triples terms, columns in name order."""
+        """Decoded bindings (this rank's share when the query ran on several GPUs): sorted list of tuples
+        of raw N-Triples terms, columns in name order."""
         ids = self.ids()
         order = sorted(range(len(self.columns)), key=lambda i: self.columns[i])
         flat = ids[:, order].reshape(-1)
@@ -157,7 +165,7 @@ class QueryResult:
             else:
                 out_flat.append(self._e.lib.dx_result_virtual_term(self._h, int(v)).decode())
         nc = len(order)
-        return sorted(tuple(out_flat[i * nc:(i + 1) * nc]) for i in range(self.count)), [self.columns[i] for i in order]
+        return sorted(tuple(out_flat[i * nc:(i + 1) * nc]) for i in range(self.local_rows)), [self.columns[i] for i in order]
 
     def close(self):
         if self._h:
@@ -307,6 +315,24 @@ class Engine:
 
     def unload_all(self):
         self._check(self.lib.dx_unload_all(self.ctx))
+
+    # ---- several GPUs ---------------------------------------------------------------------
+    def set_comm(self, comm):
+        """comm: an object with a `struct` attribute holding a dx_comm (opus_amd.host.comm.TorchComm), or None."""
+        self._comm = comm  # keeps the callbacks alive
+        self._check(self.lib.dx_set_comm(self.ctx, ctypes.byref(comm.struct) if comm is not None else None))
+
+    def declare_remote_table(self, key: str):
+        self._check(self.lib.dx_declare_remote_table(self.ctx, key.encode()))
+
+    def table_stats(self, key: str):
+        out = (c_uint64 * 3)()
+        self._check(self.lib.dx_table_stats(self.ctx, key.encode(), out))
+        return [int(out[0]), int(out[1]), int(out[2])]
+
+    def set_table_stats(self, key: str, stats):
+        arr = (c_uint64 * 3)(int(stats[0]), int(stats[1]), int(stats[2]))
+        self._check(self.lib.dx_set_table_stats(self.ctx, key.encode(), arr))
 
     def query(self, sql: str, mode: int = DX_QUERY_COUNT) -> QueryResult:
         h = c_void_p(None)

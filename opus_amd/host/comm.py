@@ -1,0 +1,145 @@
+"""The three collectives the library asks the host for when a query runs on several GPUs, over
+torch.distributed: RCCL ("nccl") on device buffers in production, gloo through host copies in tests.
+
+The library is handed plain C function pointers (struct dx_comm in include/diaeresis_hip.h); this module
+keeps the ctypes trampolines alive for as long as the communicator object lives.
+"""
+from __future__ import annotations
+
+import ctypes
+import sys
+import traceback
+from ctypes import CFUNCTYPE, POINTER, c_int, c_uint64, c_void_p
+
+import numpy as np
+
+COUNTS_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), POINTER(c_uint64))
+EXCHANGE_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, POINTER(c_uint64), c_void_p, POINTER(c_uint64), c_int)
+ALLREDUCE_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), c_int)
+
+
+class DxComm(ctypes.Structure):
+    _fields_ = [("rank", c_int), ("world", c_int), ("user", c_void_p), ("exchange_counts", COUNTS_FN),
+                ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN)]
+
+
+class _DevicePointer:
+    """Lets torch wrap memory the library owns without copying it."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def device_tensor(ptr: int, n: int, elem_bytes: int):
+    import torch
+    if elem_bytes == 8:
+        dtype, typestr = torch.int64, "<i8"
+    elif elem_bytes == 4:
+        dtype, typestr = torch.int32, "<i4"
+    else:
+        dtype, typestr, n = torch.uint8, "|u1", n * elem_bytes
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device="cuda")
+    return torch.as_tensor(_DevicePointer(ptr, n, typestr), device="cuda")
+
+
+class TorchComm:
+    """dx_comm over the default torch.distributed process group (or `group`)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self._fns = (COUNTS_FN(self._counts), EXCHANGE_FN(self._exchange), ALLREDUCE_FN(self._allreduce))
+        self.struct = DxComm(self.rank, self.world, None, *self._fns)
+
+    # every callback returns 0, or 1 after printing the exception: the library turns that into DX_E_IO
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception:  # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    def _counts(self, user, send, recv):
+        def run():
+            import torch
+            mine = torch.tensor([int(send[p]) for p in range(self.world)], dtype=torch.int64)
+            if self.on_device:
+                mine = mine.cuda()
+            everyone = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(everyone, mine, group=self.group)
+            for p in range(self.world):
+                recv[p] = int(everyone[p][self.rank])
+        return self._guard(run)
+
+    def _exchange(self, user, send_dev, send_counts, recv_dev, recv_counts, elem_bytes):
+        def run():
+            import torch
+            scale = 1 if elem_bytes in (4, 8) else elem_bytes
+            sc = [int(send_counts[p]) * scale for p in range(self.world)]
+            rc = [int(recv_counts[p]) * scale for p in range(self.world)]
+            send_t = device_tensor(send_dev or 0, sum(sc) // scale, elem_bytes)
+            recv_t = device_tensor(recv_dev or 0, sum(rc) // scale, elem_bytes)
+            if self.on_device:
+                self.dist.all_to_all_single(recv_t, send_t, rc, sc, group=self.group)
+                torch.cuda.synchronize()
+                return
+            # gloo has no all-to-all: host copies and pairwise sends (tests only)
+            hs = send_t.cpu()
+            hr = torch.empty(sum(rc), dtype=hs.dtype)
+            reqs, so, ro = [], 0, 0
+            for p in range(self.world):
+                if p == self.rank:
+                    hr[ro:ro + rc[p]] = hs[so:so + sc[p]]
+                else:
+                    if sc[p]:
+                        reqs.append(self.dist.isend(hs[so:so + sc[p]].contiguous(), p, group=self.group))
+                    if rc[p]:
+                        reqs.append(self.dist.irecv(hr[ro:ro + rc[p]], p, group=self.group))
+                so += sc[p]
+                ro += rc[p]
+            for r in reqs:
+                r.wait()
+            if hr.numel():
+                recv_t.copy_(hr)
+            torch.cuda.synchronize()
+        return self._guard(run)
+
+    def _allreduce(self, user, values, n):
+        def run():
+            import torch
+            t = torch.tensor([int(values[i]) for i in range(n)], dtype=torch.int64)
+            if self.on_device:
+                t = t.cuda()
+            self.dist.all_reduce(t, group=self.group)
+            for i in range(n):
+                values[i] = int(t[i])
+        return self._guard(run)
+
+
+def load_tables_sharded(engine, comm: TorchComm, keys, owner) -> int:
+    """Each key ("PPPPP-_3=<pred>") is loaded on the rank `owner(partition number)` returns and declared as
+    remote elsewhere; the owners' row / distinct counts are then shared, so that every rank plans alike.
+    Returns the rows loaded over all ranks."""
+    import torch
+    keys = list(dict.fromkeys(keys))
+    stats = np.zeros((len(keys), 3), dtype=np.int64)
+    for i, key in enumerate(keys):
+        if owner(int(key.split("-", 1)[0])) == comm.rank:
+            engine.load_table(key)
+            stats[i] = engine.table_stats(key)
+        else:
+            engine.declare_remote_table(key)
+    t = torch.from_numpy(stats)
+    if comm.on_device:
+        t = t.cuda()
+    comm.dist.all_reduce(t, group=comm.group)  # one owner per table: the sum is the owner's numbers
+    stats = t.cpu().numpy()
+    for i, key in enumerate(keys):
+        engine.set_table_stats(key, stats[i])
+    return int(stats[:, 0].sum())

@@ -1,0 +1,88 @@
+"""One rank of the multi-GPU query test (launched by test_gpu_sharded.py through torch.distributed.run).
+
+Every rank partitions the same LUBM-1 text (ids are deterministic, so the dictionaries agree), keeps only
+the tables of the first-level partitions it owns, and the ranks answer every query together. Rank 0 also
+answers alone over all tables and writes both results as JSON.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main(out_path):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("DX_TEST_BACKEND", "gloo"))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT, Engine
+    from opus_amd.host import shard, translator as T
+    from opus_amd.host.comm import TorchComm, load_tables_sharded
+    from oracle.query_oracle import clean_table_name, parse_translated_file
+    from parity_util import engine_artifacts
+
+    arr, _ = lubm.generate(0, 1, seed=0, ontology=0, degree_pool=3)
+    ci = lubm.class_index_text(4, 0)
+    e = Engine(0)
+    e.partition_text(arr, ci, 4)
+    art = engine_artifacts(e)
+    ni = {}
+    for u, c in art["node_index"]:
+        ni.setdefault(u, []).append(c)
+    cidx = T.load_class_index(ci)
+    statements = {}
+    for name, text in sorted(lubm.queries(0).items()):
+        qm, parts, _ = parse_translated_file(T.translate_query(name, text, lambda u: ni.get(u, []), cidx, art["partition_stat"]))
+        statements[name] = (next(iter(qm.values())), parts)
+    # a join on two columns (the same predicate as two first-level partitions hold it) and a cross product
+    O = "_http___www_lehigh_edu__zhp2_2004_0401_univ_bench_owl_"
+    adv = [k for k in ("%05d-_3=%sadvisor_" % (q, O) for q in range(4)) if (k.split("-")[0], k.split("-", 1)[1]) in art["vp"]]
+    if len(adv) >= 2:
+        statements["two_column_key"] = (
+            "SELECT tab0.X AS X,tab0.Y AS Y FROM (SELECT s AS X, o AS Y FROM %s) AS tab0, (SELECT s AS X, o AS Y FROM %s) AS tab1 "
+            "WHERE tab0.X=tab1.X AND tab0.Y=tab1.Y " % (clean_table_name(adv[0]), clean_table_name(adv[1])), adv[:2])
+    q1_sql, q1_parts = statements["Q1.txt"]
+    statements["cross_product"] = (
+        "SELECT tab0.X AS X,tab1.Y AS Y FROM (SELECT s AS X FROM %s WHERE o == '<http://www.Department0.University0.edu/GraduateCourse0>') AS tab0, "
+        "(SELECT s AS Y FROM %s WHERE o == '<http://www.Department0.University0.edu/GraduateCourse1>') AS tab1 " %
+        tuple(clean_table_name(p) for p in [p for p in q1_parts if "takescourse" in p] * 2), q1_parts)
+
+    comm = TorchComm()
+    owner = lambda q: shard.partition_owner(q, world)  # noqa: E731
+    results = {}
+    for name, (sql, parts) in statements.items():
+        # together
+        e.set_comm(comm)
+        e.unload_all()
+        loaded = load_tables_sharded(e, comm, parts, owner)
+        rc = e.query(sql, DX_QUERY_COUNT)
+        rb = e.query(sql, DX_QUERY_BINDINGS)
+        rows, cols = rb.rows()
+        shares = [None] * world
+        dist.all_gather_object(shares, rows)
+        entry = {"count": rc.count, "count_bindings": rb.count, "local_rows": rb.local_rows, "columns": cols, "loaded": loaded,
+                 "rows": sorted(tuple(r) for sh in shares for r in sh), "share_sizes": [len(sh) for sh in shares],
+                 "plan": rb.plan}
+        # alone
+        if rank == 0:
+            e.set_comm(None)
+            e.unload_all()
+            alone_loaded = sum(e.load_table(p) for p in dict.fromkeys(parts))
+            ra = e.query(sql, DX_QUERY_BINDINGS)
+            arows, acols = ra.rows()
+            entry["alone"] = {"count": ra.count, "columns": acols, "rows": [tuple(r) for r in arows], "loaded": alone_loaded}
+        results[name] = entry
+        dist.barrier()
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(results, f)
+    e.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -59,3 +59,38 @@ def test_two_ranks_shard_and_combine():
     assert [shard.partition_owner(q, 2) for q in range(5)] == [0, 1, 0, 1, 0]
     with pytest.raises(ValueError):
         shard.university_block(2, 2, 1)
+
+
+def _comm_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+        from opus_amd.host.comm import TorchComm
+        c = TorchComm()
+        st = c.struct
+        # the library calls these through the C function pointers: do the same
+        send = (ctypes.c_uint64 * world)(*[100 * rank + p for p in range(world)])
+        recv = (ctypes.c_uint64 * world)()
+        assert st.exchange_counts(None, send, recv) == 0
+        vals = (ctypes.c_uint64 * 2)(rank + 1, 10)
+        assert st.allreduce_sum(None, vals, 2) == 0
+        out.put((rank, list(recv), list(vals), st.rank, st.world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_callbacks_over_gloo():
+    """The count exchange and the sum the library asks the host for, through their C function pointers."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == (0, [0, 100], [3, 20], 0, 2)     # recv[p] = what p addressed to me
+    assert got[1] == (1, [1, 101], [3, 20], 1, 2)

@@ -1,0 +1,44 @@
+"""Queries answered by two ranks together (tables split by first-level partition, joins through the
+exchange) against the same engine answering alone. Both ranks share the one GPU of the test box and talk
+over gloo; on a multi-GPU node the same code runs over RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_answer_like_one(tmp_path):
+    out = tmp_path / "sharded.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sharded_query_worker.py"), str(out)]
+    env = dict(os.environ, DX_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.load(open(out))
+    assert len(res) >= 14
+    spread = 0
+    for name, r in res.items():
+        a = r["alone"]
+        assert r["count"] == r["count_bindings"] == a["count"] == len(a["rows"]), name
+        assert r["columns"] == a["columns"], name
+        assert [tuple(x) for x in r["rows"]] == [tuple(x) for x in a["rows"]], name  # merged shares == single-GPU bindings
+        assert r["loaded"] == a["loaded"], name
+        assert sum(r["share_sizes"]) == r["count"]
+        spread += all(s > 0 for s in r["share_sizes"])
+    assert spread >= 5  # the shuffles really spread the larger results over both ranks
+    assert "remote" in res["Q2.txt"]["plan"] and "local" in res["Q2.txt"]["plan"]
