@@ -111,6 +111,61 @@ def cpu_baseline():
             "query_geomean_ms": geo}
 
 
+def sharded_query_leg(args, eng0, plans, qnames, want_counts, rank, world, local_rank, barrier):
+    """Rank 0 writes its partitions as the reference lays them out; every rank opens that layout (one
+    dictionary), loads the tables of the first-level partitions it owns, and all ranks answer the 13 queries
+    together. Returns rank 0's timings; the counts must equal the ones rank 0 got alone."""
+    import shutil
+    import tempfile
+
+    import torch.distributed as dist
+    from opus_amd.engine import DX_QUERY_COUNT, Engine
+    from opus_amd.host import shard
+    from opus_amd.host.comm import TorchComm, load_tables_sharded
+    box = [tempfile.mkdtemp(prefix="dx_sharded_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    base = box[0]
+    try:
+        if rank == 0:
+            eng0.write_layout(base, "bench", os.path.join(base, "bench_local"))
+        barrier()
+        names = [None]
+        if rank == 0:
+            names[0] = (plans, want_counts)
+        dist.broadcast_object_list(names, src=0)   # every rank runs rank 0's statements against rank 0's data
+        plans0, want0 = names[0]
+        e = Engine(local_rank)
+        e.open_dataset(base, "bench", args.partitions)
+        comm = TorchComm()
+        e.set_comm(comm)
+        times, got = {n: [] for n in qnames}, {}
+        for it in range(args.warmup + args.steps):
+            for n in qnames:
+                sql, parts = plans0[n]
+                e.unload_all()
+                load_tables_sharded(e, comm, parts, lambda q: shard.partition_owner(q, world))
+                barrier()
+                t0 = time.perf_counter()
+                r = e.query(sql, DX_QUERY_COUNT)
+                dt = (time.perf_counter() - t0) * 1e3
+                got[n] = r.count
+                r.close()
+                if it >= args.warmup:
+                    times[n].append(dt)
+        e.close()
+        bad = {n: (got[n], want0[n]) for n in qnames if got[n] != want0[n]}
+        if bad:
+            raise RuntimeError("sharded query counts differ from the single-GPU counts: %r" % bad)
+        med = {n: float(np.median(times[n])) for n in qnames}
+        geo = math.exp(sum(math.log(max(v, 1e-9)) for v in med.values()) / len(med))
+        return {"geomean_ms": geo, "query_ms": med, "dataset": "rank 0's block, tables owned by partition %% %d" % world,
+                "counts_equal_single_gpu": True}
+    finally:
+        barrier()
+        if rank == 0:
+            shutil.rmtree(base, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +174,11 @@ def main():
     ap.add_argument("--universities", type=int, default=100, help="universities per GPU (100 = LUBM-100, ~14 M triples)")
     ap.add_argument("--partitions", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-queries", action="store_true",
+                    help="extra leg for --gpus N > 1: rank 0's partitions are split over the ranks by first-level "
+                         "partition and the 13 queries run on all GPUs together (hash exchange before every join)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -130,9 +190,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from opus_amd import lubm
     from opus_amd.engine import DX_QUERY_COUNT, Engine
@@ -197,8 +262,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_begin
 
-    elapsed, part_total, total_triples = shard.combine_timings(elapsed, sum(part_s), n_triples, device)
-    counts = shard.combine_counts({n: int(counts[n]) for n in qnames}, device)
+    red_device = device if args.backend == "nccl" else torch.device("cpu")
+    elapsed, part_total, total_triples = shard.combine_timings(elapsed, sum(part_s), n_triples, red_device)
+    local_counts = {n: int(counts[n]) for n in qnames}
+    counts = shard.combine_counts(local_counts, red_device)
+    sharded = sharded_query_leg(args, eng, plans, qnames, local_counts, rank, world, local_rank, barrier) if (args.sharded_queries and world > 1) else None
 
     if rank == 0:
         med = lambda xs: float(np.median(xs))  # noqa: E731
@@ -257,6 +325,8 @@ def main():
                          "traffic": None},
             "kernel_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kernels.items()},
         }
+        if sharded is not None:
+            out["sharded_queries"] = sharded
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
