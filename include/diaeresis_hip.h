@@ -128,6 +128,13 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
  * entry of the `partitions` line ("00001-_3=<sanitised predicate>"): makes the table resident in HBM and
  * visible to SQL under "table" + key with '-' -> '_' and '=' -> '_E_' (:216). Memoised like dataMap (:327-337). */
 int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows);
+/* For tables that reach the host as strings (Parquet written by the Scala tools, decoded by the host's
+ * Parquet library): installs a dictionary of n_terms distinct terms (term i = bytes[offsets[i], offsets[i+1]),
+ * its id is i), replacing any dictionary and every loaded table, then tables are registered by id.
+ * Together they replace spark.read.load(...).as[(String, String)] in QueryProcessor.loadDataset
+ * (QueryProcessor.scala:322-333). */
+int dx_dictionary_load(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n_terms);
+int dx_load_table_ids(dx_ctx* ctx, const char* partition_key, const int64_t* s, const int64_t* o, uint64_t rows);
 /* Replaces unloadTables (QueryProcessor.scala:239-251). */
 int dx_unload_all(dx_ctx* ctx);
 
@@ -150,6 +157,7 @@ const char* dx_result_virtual_term(dx_result* r, int64_t id);
 const char* dx_result_plan(dx_result* r);
 /* Device time of the statement in milliseconds (hipEvents around the launches). */
 double dx_result_device_ms(dx_result* r);
+/* A result holds device memory of its context: free it before dx_free of that context. */
 void dx_result_free(dx_result* r);
 
 /* ---- query processor on several GPUs ------------------------------------------------------------------

@@ -653,6 +653,59 @@ int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
   });
 }
 
+int dx_dictionary_load(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n_terms) {
+  return guard(ctx, [&] {
+    if (!offsets || (!bytes && n_terms && offsets[n_terms])) throw DxError(DX_E_INVAL, "null argument");
+    if (n_terms >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 terms");
+    for (uint64_t i = 0; i < n_terms; ++i)
+      if (offsets[i + 1] < offsets[i]) throw DxError(DX_E_INVAL, "offsets must not decrease");
+    if (offsets[0] != 0) throw DxError(DX_E_INVAL, "offsets[0] must be 0");
+    ctx->catalog.clear();
+    ctx->table_stats.clear();
+    ctx->part = PartitionState();
+    Dictionary nd;
+    nd.n_terms = n_terms;
+    nd.seed = 0x243F6A8885A308D3ull;
+    nd.pool_off = DevBuf<uint64_t>(ctx->pool, n_terms + 1);
+    nd.pool = DevBuf<uint8_t>(ctx->pool, offsets[n_terms] + 16);
+    DX_HIP(hipMemcpy(nd.pool_off.p, offsets, (n_terms + 1) * 8, hipMemcpyHostToDevice));
+    if (offsets[n_terms]) DX_HIP(hipMemcpy(nd.pool.p, bytes, offsets[n_terms], hipMemcpyHostToDevice));
+    ctx->dict = std::move(nd);
+    dict_build_table(ctx);  // fails if two terms are equal
+    ctx->ds_base.clear();
+    ctx->ds_name.clear();
+  });
+}
+
+int dx_load_table_ids(dx_ctx* ctx, const char* partition_key, const int64_t* s, const int64_t* o, uint64_t rows) {
+  return guard(ctx, [&] {
+    if (!partition_key || (rows && (!s || !o))) throw DxError(DX_E_INVAL, "null argument");
+    if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
+    if (rows >= (1ull << 32)) throw DxError(DX_E_RANGE, "table with 2^32 rows or more");
+    for (uint64_t i = 0; i < rows; ++i)
+      if (s[i] < 0 || o[i] < 0 || (uint64_t)s[i] >= ctx->dict.n_terms || (uint64_t)o[i] >= ctx->dict.n_terms)
+        throw DxError(DX_E_RANGE, "row " + std::to_string(i) + " names a term id outside the dictionary");
+    const std::string key = partition_key, view = view_name(key);
+    ctx->catalog.erase(view);
+    ctx->table_stats.erase(key);
+    CatalogTable t;
+    t.key = key;
+    t.view = view;
+    t.rows = rows;
+    t.own_s = DevBuf<int64_t>(ctx->pool, rows);
+    t.own_o = DevBuf<int64_t>(ctx->pool, rows);
+    if (rows) {
+      DX_HIP(hipMemcpy(t.own_s.p, s, rows * 8, hipMemcpyHostToDevice));
+      DX_HIP(hipMemcpy(t.own_o.p, o, rows * 8, hipMemcpyHostToDevice));
+    }
+    auto it = ctx->catalog.emplace(view, std::move(t)).first;
+    it->second.s = it->second.own_s.p;
+    it->second.o = it->second.own_o.p;
+    table_statistics(ctx, it->second);
+    ctx->table_stats[key] = {it->second.distinct_s, it->second.distinct_o};
+  });
+}
+
 int dx_set_comm(dx_ctx* ctx, const dx_comm* comm) {
   return guard(ctx, [&] {
     if (!comm || comm->world <= 1) { ctx->comm = dx_comm{0, 1, nullptr, nullptr, nullptr, nullptr}; return; }

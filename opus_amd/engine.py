@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import numpy as np
@@ -30,7 +31,7 @@ EXPORTS = [
     "dx_instance_graph_fetch", "dx_part_write_layout", "dx_open_dataset", "dx_load_table", "dx_unload_all",
     "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
-    "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
+    "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
 ]
 
 
@@ -110,6 +111,8 @@ def load_library():
         "dx_result_plan": (c_char_p, [c_void_p]),
         "dx_result_device_ms": (c_double, [c_void_p]),
         "dx_result_free": (None, [c_void_p]),
+        "dx_dictionary_load": (c_int, [c_void_p, c_void_p, u64p, c_uint64]),
+        "dx_load_table_ids": (c_int, [c_void_p, c_char_p, i64p, i64p, c_uint64]),
         "dx_set_comm": (c_int, [c_void_p, c_void_p]),
         "dx_declare_remote_table": (c_int, [c_void_p, c_char_p]),
         "dx_table_stats": (c_int, [c_void_p, c_char_p, u64p]),
@@ -184,9 +187,12 @@ class Engine:
         self.ctx = self.lib.dx_init(device)
         if not self.ctx:
             raise RuntimeError("dx_init(%d) failed: no such HIP device (this engine has no CPU path)" % device)
+        self._results = weakref.WeakSet()  # a dx_result holds memory of its context: freed before the context is
 
     def close(self):
         if self.ctx:
+            for r in list(self._results):
+                r.close()
             self.lib.dx_free(self.ctx)
             self.ctx = None
 
@@ -313,6 +319,17 @@ class Engine:
         self._check(self.lib.dx_load_table(self.ctx, key.encode(), byref(rows)))
         return rows.value
 
+    def dictionary_load(self, data: np.ndarray, offsets: np.ndarray):
+        """Installs a dictionary: term i = data[offsets[i]:offsets[i+1]] (uint8 bytes, uint64 offsets)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self.lib.dx_dictionary_load(self.ctx, data.ctypes.data_as(c_void_p), _p(offsets, c_uint64), offsets.size - 1))
+
+    def load_table_ids(self, key: str, s, o):
+        s = np.ascontiguousarray(s, dtype=np.int64)
+        o = np.ascontiguousarray(o, dtype=np.int64)
+        self._check(self.lib.dx_load_table_ids(self.ctx, key.encode(), _p(s), _p(o), s.size))
+
     def unload_all(self):
         self._check(self.lib.dx_unload_all(self.ctx))
 
@@ -337,4 +354,6 @@ class Engine:
     def query(self, sql: str, mode: int = DX_QUERY_COUNT) -> QueryResult:
         h = c_void_p(None)
         self._check(self.lib.dx_query(self.ctx, sql.encode("utf-8", "surrogateescape"), mode, byref(h)))
-        return QueryResult(self, h)
+        r = QueryResult(self, h)
+        self._results.add(r)
+        return r

@@ -1,0 +1,78 @@
+"""The Parquet side of the reference's layout: file names, schemas, codec, and a write/read round trip of
+the oracle's artefacts (no GPU: the writers take plain id arrays and term strings)."""
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pyarrow.parquet as pq
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _ids(strings, index):
+    return np.array([index[s] for s in strings], dtype=np.int64)
+
+
+def test_layout_round_trip(tmp_path):
+    from opus_amd.host import parquet_io as P
+    from oracle import dap_oracle
+    g = json.load(open(os.path.join(HERE, "golden", "appendix_c.json")))
+    ref = dap_oracle.run_dap(g["instances"], g["class_index"], g["n_partitions"])
+    n = g["n_partitions"]
+    all_terms = sorted({x for part in ref["parts"] for row in part for x in row})
+    index = {t: i for i, t in enumerate(all_terms)}
+    terms = P.Terms.from_strings(all_terms)
+    base = str(tmp_path) + "/"
+    for q, part in enumerate(ref["parts"]):
+        rows = sorted(part)
+        if rows:
+            P.write_partition_file(base, "ds", n, q, terms, _ids([r[0] for r in rows], index), _ids([r[1] for r in rows], index),
+                                   _ids([r[2] for r in rows], index))
+    by_pred = {}
+    for q, part in enumerate(ref["parts"]):
+        for s, o, p in sorted(part):
+            by_pred.setdefault((q, p), []).append((s, o))
+    for (q, p), rows in by_pred.items():
+        P.write_vp_table(base, "ds", n, q, p, terms, _ids([r[0] for r in rows], index), _ids([r[1] for r in rows], index))
+    ni = sorted(ref["node_index"])
+    P.write_node_index(base, "ds", n, terms, _ids([r[0] for r in ni], index), _ids([r[1] for r in ni], index))
+
+    root = P.cluster_dir(base, "ds", n)
+    part_files = sorted(f for f in os.listdir(root) if f.startswith("part-"))
+    assert all(re.fullmatch(r"part-\d{5}-[0-9a-f-]{36}-c000\.snappy\.parquet", f) for f in part_files)
+    assert os.path.exists(os.path.join(root, "_SUCCESS"))
+    for f in part_files:
+        q = int(f[5:10])
+        md = pq.ParquetFile(os.path.join(root, f))
+        assert md.schema_arrow.names == ["_1", "_2", "_3"]
+        assert all(str(t) == "string" for t in md.schema_arrow.types)
+        col = md.metadata.row_group(0).column(0)
+        assert col.compression == "SNAPPY" and col.physical_type == "BYTE_ARRAY"
+        assert not (md.metadata.metadata or {}).get(b"ARROW:schema")
+        t = md.read()
+        assert set(zip(t["_1"].to_pylist(), t["_2"].to_pylist(), t["_3"].to_pylist())) == ref["parts"][q]
+    # VP directories: Hive-style names, rows equal to the oracle's tables
+    assert sorted(P.vp_table_keys(base, "ds", n)) == sorted("%s-%s" % k for k in ref["vp"])
+    for (pname, sub), rows in ref["vp"].items():
+        t = P.read_table(os.path.join(root, pname, sub))
+        assert t.schema.names == ["_1", "_2"]
+        assert sorted(zip(t["_1"].to_pylist(), t["_2"].to_pylist())) == sorted(rows)
+        assert os.path.exists(os.path.join(root, pname, sub, "_SUCCESS"))
+    t = P.read_table(os.path.join(base, "ds_data", "node_index_%d" % n))
+    assert t.schema.names == ["uri", "uriType"]
+    assert set(zip(t["uri"].to_pylist(), t["uriType"].to_pylist())) == ref["node_index"]
+
+
+def test_vp_index_file(tmp_path):
+    from opus_amd.host import parquet_io as P
+    terms = P.Terms.from_strings(["<a>", "<b>", "<http://x/P-1>", "<http://x/q>"])
+    P.write_vp_index(str(tmp_path) + "/", "ds", 4, 2, terms, np.array([0, 0, 1, 0]), np.array([0, 1, 1, 0]),
+                     ["<http://x/P-1>", "<http://x/q>", "<http://x/q>", "<http://x/P-1>"])
+    d = os.path.join(str(tmp_path), "ds_data", "classSubPart_index_4__00002")
+    t = P.read_table(d)
+    assert t.schema.names == ["uri", "parts"]
+    got = dict(zip(t["uri"].to_pylist(), t["parts"].to_pylist()))
+    assert got == {"<a>": "o_http___x_q_,s_http___x_p_1_", "<b>": "o_http___x_q_"}
+    assert len(glob.glob(os.path.join(d, "part-00000-*-c000.snappy.parquet"))) == 1
