@@ -298,6 +298,16 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM-side bytes per launch of that kernel from the PMC passes kept under profiles/ (same command,
+        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; see profiles/summarise.py); null when the
+        # workload is not the profiled one
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path) and args.universities == 100 and args.partitions == 8:
+            pmc = json.load(open(pmc_path))
+            names = [w for w in dom.replace("+", " ").split() if w.startswith("k_")]
+            if names and all(nm in pmc for nm in names):
+                traffic = sum(pmc[nm]["bytes"] for nm in names)
         # algorithmic bytes of the whole partitioner per SURVEY 8(d): text once + R*(24+16) B per triple
         R = st.n_rows / max(1, st.n_triples)
         hp1_alg_bytes = n_bytes + st.n_rows * 40
@@ -322,7 +332,7 @@ def main():
             "query_counts": {n: int(counts[n]) for n in qnames},
             "roofline": {"bound": "hbm", "kernel": dom, "ms": dom_ms, "algorithmic_bytes": dom_bytes,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None},
+                         "traffic": traffic},
             "kernel_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kernels.items()},
         }
         if sharded is not None:

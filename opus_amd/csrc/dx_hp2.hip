@@ -15,6 +15,7 @@
 //     its optimistic capacity is detected there (its counter holds the exact size needed) and the
 //     statement is run again with that capacity.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <functional>
 #include <sstream>
@@ -469,8 +470,10 @@ struct QueryHostBlock {
 };
 
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
+  const auto t_host0 = std::chrono::steady_clock::now();
   const SqlQuery q = parse_sql(sql);
   Plan plan = make_plan(ctx, q);
+  const double plan_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
   if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
   for (auto& r : plan.rels)
     for (auto& a : r.arms)
@@ -612,6 +615,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       DX_HIP(hipStreamSynchronize(s));
       DX_HIP(hipGetLastError());
       std::ostringstream explain;
+      explain << "parse+plan " << (long)plan_us << " us\n";
       for (int k = 0; k < nsteps; ++k) {
         const PlanRel& r = plan.rels[k];
         explain << (k ? "join " : "scan ");
