@@ -180,8 +180,18 @@ typedef struct dx_comm {
                   int elem_bytes);
   /* element-wise sum over all ranks, result on every rank */
   int (*allreduce_sum)(void* user, uint64_t* values, int n);
+  /* the partitioner's collectives (may be NULL when only queries run on several GPUs):
+   * recv_dev = the ranks' send buffers one after another in rank order (recv_counts[p] elements from p) */
+  int (*allgather)(void* user, const void* send_dev, uint64_t send_count, void* recv_dev, const uint64_t* recv_counts, int elem_bytes);
+  /* element-wise sum of a device array of n elements of 1 or 8 bytes, in place, result on every rank */
+  int (*allreduce_sum_dev)(void* user, void* dev, uint64_t n, int elem_bytes);
 } dx_comm;
-/* comm == NULL or world == 1 returns the context to single-GPU execution. */
+/* comm == NULL or world == 1 returns the context to single-GPU execution.
+ * With a communicator that has all five collectives, dx_partition_device / dx_partition_file are collective
+ * too: every rank passes its own part of the input text (cut at line ends) and the same class index; the
+ * ranks agree on one dictionary (same ids everywhere) and rank r ends up holding the first-level
+ * partitions q with q % world == r of the whole input, as partitionClusters' CustomPartitioner routes
+ * them (DAP.scala:541-551), with their VP tables and VP index, and its share of the node index. */
 int dx_set_comm(dx_ctx* ctx, const dx_comm* comm);
 /* A table of the `partitions` line that another rank holds (same key syntax as dx_load_table). */
 int dx_declare_remote_table(dx_ctx* ctx, const char* partition_key);

@@ -407,8 +407,11 @@ static void instance_graph(dx_ctx* ctx, std::vector<int64_t>& vterms, std::vecto
 int dx_instance_graph_sizes(dx_ctx* ctx, int64_t* n_vertices, int64_t* n_edges) {
   return guard(ctx, [&] {
     if (!ctx->part.valid) throw DxError(DX_E_INVAL, "no partition run");
-    *n_vertices = (int64_t)ctx->part.stats.n_vertices;
-    *n_edges = (int64_t)ctx->part.stats.n_edges;
+    // counted from what this context holds: with several ranks that is the rank's share of the edges
+    std::vector<int64_t> v, es, ed, ep;
+    instance_graph(ctx, v, &es, &ed, &ep);
+    *n_vertices = (int64_t)v.size();
+    *n_edges = (int64_t)es.size();
   });
 }
 
@@ -708,7 +711,7 @@ int dx_load_table_ids(dx_ctx* ctx, const char* partition_key, const int64_t* s, 
 
 int dx_set_comm(dx_ctx* ctx, const dx_comm* comm) {
   return guard(ctx, [&] {
-    if (!comm || comm->world <= 1) { ctx->comm = dx_comm{0, 1, nullptr, nullptr, nullptr, nullptr}; return; }
+    if (!comm || comm->world <= 1) { ctx->comm = dx_comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; return; }
     if (comm->rank < 0 || comm->rank >= comm->world || !comm->exchange_counts || !comm->exchange || !comm->allreduce_sum)
       throw DxError(DX_E_INVAL, "dx_set_comm: rank out of range or a collective is missing");
     if (comm->world > 64) throw DxError(DX_E_RANGE, "dx_set_comm: more than 64 ranks");

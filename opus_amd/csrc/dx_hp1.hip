@@ -777,8 +777,8 @@ __device__ __forceinline__ Unpacked unpack(uint64_t k, int bits_term) {
 // distinct triples, distinct edges and node-index rows.
 __global__ void __launch_bounds__(256)
 k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
-        const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, uint64_t* __restrict__ mask,
-        uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges*/) {
+        const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, uint64_t owned /*partitions this rank keeps*/,
+        uint64_t* __restrict__ mask, uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges*/) {
   // Grid-stride: the two counters are hit once per block at the end, and the grid is a few thousand blocks.
   // (Atomics of many blocks on one word are served one after another by a single L2 channel.)
   uint32_t uq = 0, ed = 0;
@@ -787,7 +787,6 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
     uint64_t m = 0;
     uint8_t nf = 0;
     if (i == 0 || keys[i - 1] != k) {
-      ++uq;
       const Unpacked t = unpack(k, bits_term);
       if (t.pidx == type_pidx) {
         m = (flags[t.s] & kFlagEdge) ? Pm[t.o] : 0;
@@ -795,9 +794,17 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
       } else if (flags[t.o] & kFlagLiteral) {
         m = (flags[t.s] & kFlagEdge) ? M[t.s] : 0;
       } else {
-        ++ed;
         m = M[t.s] | M[t.o];
       }
+      // With several ranks a triple reaches every owner of one of its partitions: the owner of the lowest
+      // one counts it and keeps its node-index row (one GPU: owned = all ones, so always).
+      const bool mine = m == 0 ? owned == ~0ull : ((m & (~m + 1)) & owned) != 0;
+      if (mine) {
+        ++uq;
+        if (t.pidx != type_pidx && !(flags[t.o] & kFlagLiteral)) ++ed;
+      }
+      nf = nf && mine;
+      m &= owned;
     }
     mask[i] = m;
     node_flag[i] = nf;
@@ -1011,6 +1018,143 @@ __global__ void k_vpi_bases(const uint64_t* __restrict__ keys, uint32_t n, int s
   base[q] = lo;
 }
 
+// ---- several GPUs: one dictionary for all ranks, triples routed to the owners of their partitions -----------
+// The ranks' local term pools laid one after another are treated as a text of E entries: entry e of rank r is
+// bytes [base[r] + off_r[j], base[r] + off_r[j+1]). The dictionary kernels above then give every distinct
+// string one id, in order of first appearance in that concatenation: the same ids on every rank.
+__global__ void __launch_bounds__(256)
+k_entry_spans(const uint8_t* __restrict__ gpool, const uint64_t* __restrict__ goff /*each rank's n_r + 1 offsets, concatenated*/,
+              const uint64_t* __restrict__ entry_base /*[W+1] first entry of rank r*/, const uint64_t* __restrict__ byte_base /*[W]*/,
+              int world, uint64_t n_entries, uint64_t seed, uint64_t* __restrict__ e_rep, uint64_t* __restrict__ e_hash) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  int r = 0;
+  while (r + 1 < world && e >= entry_base[r + 1]) ++r;
+  const uint64_t j = e - entry_base[r];
+  const uint64_t* off = goff + entry_base[r] + r;  // rank r's offsets start after r earlier (n + 1)-arrays
+  const uint64_t b = byte_base[r] + off[j], len = off[j + 1] - off[j];
+  e_rep[e] = (b << kRepLenBits) | len;
+  e_hash[e] = hash_range(gpool, b, b + len, seed);
+}
+
+// first[e] = 1 when entry e is its slot's representative; the others are compared with it byte by byte
+__global__ void __launch_bounds__(256)
+k_entry_verify(const uint8_t* __restrict__ gpool, const uint64_t* __restrict__ e_rep, const uint32_t* __restrict__ e_slot, uint64_t n_entries,
+               const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const uint64_t mine = e_rep[e], r = ht[e_slot[e]].val;
+  first[e] = mine == r;
+  if (mine == r) return;
+  const uint64_t lm = mine & ((1ull << kRepLenBits) - 1);
+  if (lm != (r & ((1ull << kRepLenBits) - 1)) || diff_global(gpool + (mine >> kRepLenBits), gpool + (r >> kRepLenBits), lm)) *collision = 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_entry_ids(const uint32_t* __restrict__ e_slot, const DictSlot* __restrict__ ht, uint64_t n_entries, uint32_t* __restrict__ gid) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_entries) gid[e] = (uint32_t)ht[e_slot[e]].val;
+}
+
+__global__ void __launch_bounds__(256)
+k_remap(uint32_t* __restrict__ ids, const uint32_t* __restrict__ map, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = map[ids[i]];
+}
+
+// the per-term facts of k_encode, from records that already carry their final ids
+__global__ void __launch_bounds__(256)
+k_facts(const uint32_t* __restrict__ S, const uint32_t* __restrict__ P, const uint32_t* __restrict__ O, const uint8_t* __restrict__ kind,
+        uint32_t n_rec, uint8_t* __restrict__ is_vertex, uint8_t* __restrict__ has_edge, uint8_t* __restrict__ is_literal,
+        uint8_t* __restrict__ is_pred) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rec) return;
+  const uint32_t s = S[r], p = P[r], o = O[r];
+  auto set = [](uint8_t* a, uint32_t id) { if (!a[id]) a[id] = 1; };
+  set(is_pred, p);
+  const uint8_t k = kind[r];
+  set(is_vertex, s);
+  if (k == 0) { set(has_edge, s); set(is_vertex, o); set(has_edge, o); }
+  else if (k == 2) set(is_literal, o);
+}
+
+__global__ void __launch_bounds__(256) k_nonzero_u8(uint8_t* __restrict__ a, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = a[i] ? 1 : 0;
+}
+
+// M[t] = OR over the ranks' partial masks (gathered one rank after another)
+__global__ void __launch_bounds__(256)
+k_or_gathered(const uint64_t* __restrict__ gathered, int world, uint64_t n, uint64_t* __restrict__ M) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t m = 0;
+  for (int r = 0; r < world; ++r) m |= gathered[(uint64_t)r * n + i];
+  M[i] = m;
+}
+
+// Partitions of a triple (the closed form of k_place, without the duplicate test) folded into the set of
+// ranks that own one of them: bit d of the result = rank d holds a partition q of the triple, q % world == d.
+__device__ __forceinline__ uint64_t placement(const Unpacked& t, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+                                              const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M) {
+  if (t.pidx == type_pidx) return (flags[t.s] & kFlagEdge) ? Pm[t.o] : 0;
+  if (flags[t.o] & kFlagLiteral) return (flags[t.s] & kFlagEdge) ? M[t.s] : 0;
+  return M[t.s] | M[t.o];
+}
+__device__ __forceinline__ uint64_t owners_of(uint64_t m, int world) {
+  uint64_t d = 0;
+  for (; m; m &= m - 1) d |= 1ull << ((__ffsll((long long)m) - 1) % world);
+  return d;
+}
+__global__ void __launch_bounds__(256)
+k_route_count(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+              const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, int world, uint64_t* __restrict__ owners,
+              unsigned long long* __restrict__ counts) {
+  __shared__ uint32_t c[DX_MAX_PARTITIONS];
+  if (threadIdx.x < DX_MAX_PARTITIONS) c[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint64_t d = owners_of(placement(unpack(keys[i], bits_term), type_pidx, flags, Pm, M), world);
+    owners[i] = d;
+    for (uint64_t x = d; x; x &= x - 1) atomicAdd(&c[__ffsll((long long)x) - 1], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < world && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256)
+k_route_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ owners, uint32_t n, int world,
+                unsigned long long* __restrict__ cursor, uint64_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (n + stride - 1) / stride;
+  for (uint32_t rd = 0; rd < rounds; ++rd) {
+    const uint32_t i = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t d = i < n ? owners[i] : 0;
+    const uint64_t k = i < n ? keys[i] : 0;
+    for (int p = 0; p < world; ++p) {  // wave-uniform
+      const bool go = (d >> p) & 1;
+      const uint64_t b = __ballot(go);
+      if (!b) continue;
+      const int leader = __ffsll((unsigned long long)b) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(&cursor[p], (unsigned long long)__popcll(b));
+      base = __shfl(base, leader, 64);
+      if (go) out[base + __popcll(b & lt)] = k;
+    }
+  }
+}
+
+// the node bit of the flags as a byte array and back (summed over the ranks in between)
+__global__ void __launch_bounds__(256) k_node_bit_out(const uint8_t* __restrict__ flags, uint64_t n, uint8_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (flags[i] & kFlagNode) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_node_bit_in(const uint8_t* __restrict__ in, uint64_t n, uint8_t* __restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && in[i]) flags[i] |= kFlagNode;
+}
+
 int bits_for(uint64_t n) {  // bits needed for values in [0, n)
   int b = 1;
   while ((1ull << b) < n) ++b;
@@ -1138,6 +1282,113 @@ void table_statistics(dx_ctx* ctx, CatalogTable& t) {
   t.distinct_o = h[1];
 }
 
+namespace {
+void comm_ok(int rc, const char* what) {
+  if (rc != 0) throw DxError(DX_E_IO, std::string("collective failed: ") + what);
+}
+// every rank's value of a host number, in rank order
+std::vector<uint64_t> gather_u64(const dx_comm& cm, uint64_t v) {
+  std::vector<uint64_t> send(cm.world, v), recv(cm.world, 0);
+  comm_ok(cm.exchange_counts(cm.user, send.data(), recv.data()), "exchange_counts");
+  return recv;
+}
+
+// Replaces the rank's dictionary (built over its own part of the text) by the dictionary of all ranks'
+// terms and rewrites the records' term ids accordingly. On return ctx->dict and n_terms are the same on every rank.
+void globalise_dictionary(dx_ctx* ctx, uint32_t n_rec, uint32_t* S, uint32_t* P, uint32_t* O, uint32_t& n_terms) {
+  const dx_comm& cm = ctx->comm;
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  Dictionary& d = ctx->dict;
+  const int W = cm.world;
+  uint64_t local_bytes = 0;
+  DX_HIP(hipMemcpyAsync(&local_bytes, d.pool_off.p + n_terms, 8, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  const std::vector<uint64_t> n_r = gather_u64(cm, n_terms), bytes_r = gather_u64(cm, local_bytes);
+  std::vector<uint64_t> entry_base(W + 1, 0), byte_base(W + 1, 0), off_counts(W);
+  for (int r = 0; r < W; ++r) {
+    entry_base[r + 1] = entry_base[r] + n_r[r];
+    byte_base[r + 1] = byte_base[r] + bytes_r[r];
+    off_counts[r] = n_r[r] + 1;
+  }
+  const uint64_t E = entry_base[W], total_bytes = byte_base[W];
+  if (E >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 dictionary entries over all ranks");
+  if (total_bytes >= (1ull << (64 - kRepLenBits))) throw DxError(DX_E_RANGE, "term pools larger than 1 TiB");
+  DevBuf<uint8_t> gpool(pool, total_bytes + 16);
+  DevBuf<uint64_t> goff(pool, E + W);
+  comm_ok(cm.allgather(cm.user, d.pool.p, local_bytes, gpool.p, bytes_r.data(), 1), "allgather of term bytes");
+  comm_ok(cm.allgather(cm.user, d.pool_off.p, (uint64_t)n_terms + 1, goff.p, off_counts.data(), 8), "allgather of term offsets");
+  DevBuf<uint64_t> bases(pool, 2 * (W + 1));
+  DX_HIP(hipMemcpyAsync(bases.p, entry_base.data(), (W + 1) * 8, hipMemcpyHostToDevice, s));
+  DX_HIP(hipMemcpyAsync(bases.p + W + 1, byte_base.data(), (W + 1) * 8, hipMemcpyHostToDevice, s));
+  DevBuf<uint64_t> e_rep(pool, E), e_hash(pool, E);
+  DevBuf<uint32_t> e_slot(pool, E), first_scan(pool, E), coll(pool, 2);
+  DevBuf<uint8_t> first(pool, E);
+  DevBuf<uint32_t> d_total(pool, 1);
+  uint64_t cap = 1024;
+  while (cap < E + E / 2) cap <<= 1;
+  DevBuf<DictSlot> ht(pool, cap);
+  uint64_t seed = 0x243F6A8885A308D3ull;
+  uint32_t n_global = 0;
+  for (int attempt = 0;; ++attempt) {
+    if (E) hipLaunchKernelGGL(k_entry_spans, dim3(blocks(E)), dim3(256), 0, s, gpool.p, goff.p, bases.p, bases.p + W + 1, W, E, seed, e_rep.p, e_hash.p);
+    hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
+    DX_HIP(hipMemsetAsync(coll.p, 0, 8, s));
+    if (E) {
+      hipLaunchKernelGGL(k_dict_insert, dim3(blocks(E)), dim3(256), 0, s, e_hash.p, e_rep.p, E, ht.p, cap - 1, e_slot.p, coll.p + 1);
+      hipLaunchKernelGGL(k_entry_verify, dim3(blocks(E)), dim3(256), 0, s, gpool.p, e_rep.p, e_slot.p, E, ht.p, first.p, coll.p);
+    }
+    exclusive_scan_u8_u32(pool, first.p, first_scan.p, E, d_total.p, s);
+    uint32_t h_coll[2] = {0, 0};
+    DX_HIP(hipMemcpyAsync(h_coll, coll.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipMemcpyAsync(&n_global, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    // every rank sees the same entries, so every rank takes the same turns here
+    if (h_coll[1]) {
+      if (cap >= 4ull * E && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 4 slots per entry");
+      cap <<= 1;
+      ht = DevBuf<DictSlot>(pool, cap);
+      continue;
+    }
+    if (!h_coll[0]) break;
+    if (attempt >= 7) throw DxError(DX_E_RANGE, "dictionary: hash collisions persisted over 8 seeds");
+    seed = mix64(seed + 0x9E3779B97F4A7C15ull);
+  }
+  DevBuf<uint32_t> term_len(pool, (size_t)n_global + 1);
+  DevBuf<uint64_t> term_src(pool, n_global);
+  DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_global + 1) * 4, s));
+  DevBuf<uint32_t> gid(pool, E);
+  if (E) {
+    hipLaunchKernelGGL(k_dict_assign, dim3(blocks(E)), dim3(256), 0, s, e_rep.p, e_slot.p, first.p, first_scan.p, E, ht.p, term_len.p, term_src.p);
+    hipLaunchKernelGGL(k_entry_ids, dim3(blocks(E)), dim3(256), 0, s, e_slot.p, ht.p, E, gid.p);
+  }
+  Dictionary g;
+  g.n_terms = n_global;
+  g.seed = seed;
+  g.pool_off = DevBuf<uint64_t>(pool, (size_t)n_global + 1);
+  DevBuf<uint64_t> d_total64(pool, 1);
+  exclusive_scan_u32_u64(pool, term_len.p, g.pool_off.p, (size_t)n_global + 1, d_total64.p, s);
+  uint64_t g_bytes = 0;
+  DX_HIP(hipMemcpyAsync(&g_bytes, d_total64.p, 8, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  g.pool = DevBuf<uint8_t>(pool, g_bytes + 16);
+  if (n_global) hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * n_global)), dim3(256), 0, s, gpool.p, term_src.p, g.pool_off.p, (uint64_t)n_global, g.pool.p);
+  g.ht = std::move(ht);
+  g.ht_mask = cap - 1;
+  // my local id j is entry entry_base[rank] + j
+  const uint32_t* map = gid.p + entry_base[cm.rank];
+  if (n_rec) {
+    hipLaunchKernelGGL(k_remap, dim3(blocks(n_rec)), dim3(256), 0, s, S, map, (uint64_t)n_rec);
+    hipLaunchKernelGGL(k_remap, dim3(blocks(n_rec)), dim3(256), 0, s, P, map, (uint64_t)n_rec);
+    hipLaunchKernelGGL(k_remap, dim3(blocks(n_rec)), dim3(256), 0, s, O, map, (uint64_t)n_rec);
+  }
+  DX_HIP(hipStreamSynchronize(s));
+  DX_HIP(hipGetLastError());
+  ctx->dict = std::move(g);
+  n_terms = n_global;
+}
+}  // namespace
+
 void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
                    int nparts) {
   hipStream_t s = ctx->stream;
@@ -1244,9 +1495,9 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint64_t> term_src(pool, n_terms);
   DevBuf<uint32_t> S(pool, n_rec), P(pool, n_rec), O(pool, n_rec);
   ps.term_flags = DevBuf<uint8_t>(pool, ((size_t)n_terms + 4) & ~(size_t)3);
-  const size_t nt_pad = ((size_t)n_terms + 4) & ~(size_t)3;
+  size_t nt_pad = ((size_t)n_terms + 4) & ~(size_t)3;
   DevBuf<uint8_t> fact(pool, 4 * nt_pad);  // is_pred, is_vertex, has_edge, is_literal
-  uint8_t* const is_pred = fact.p;
+  uint8_t* is_pred = fact.p;
   DX_HIP(hipMemsetAsync(fact.p, 0, fact.bytes(), s));
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
@@ -1276,6 +1527,33 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   tm.mark();
   t_rep.reset(); term_src.reset(); term_len.reset();
 
+  // ---- several GPUs: one dictionary for all ranks; the per-term facts are recomputed over its ids and
+  // summed over the ranks (a fact holds if it holds anywhere). The time lands in the vertex_masks stage.
+  const dx_comm& cm = ctx->comm;
+  const bool sharded = cm.world > 1;
+  uint64_t owned = ~0ull;  // first-level partitions this rank keeps
+  if (sharded) {
+    if (!cm.allgather || !cm.allreduce_sum_dev) throw DxError(DX_E_INVAL, "the communicator lacks the partitioner's collectives");
+    owned = 0;
+    for (int q = 0; q < nparts; ++q)
+      if (q % cm.world == cm.rank) owned |= 1ull << q;
+    globalise_dictionary(ctx, n_rec, S.p, P.p, O.p, n_terms);
+    st.n_terms = n_terms;
+    nt_pad = ((size_t)n_terms + 4) & ~(size_t)3;
+    fact = DevBuf<uint8_t>(pool, 4 * nt_pad);
+    is_pred = fact.p;
+    DX_HIP(hipMemsetAsync(fact.p, 0, fact.bytes(), s));
+    if (n_rec)
+      hipLaunchKernelGGL(k_facts, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, P.p, O.p, kind.p, n_rec, fact.p + nt_pad, fact.p + 2 * nt_pad,
+                         fact.p + 3 * nt_pad, is_pred);
+    DX_HIP(hipStreamSynchronize(s));
+    comm_ok(cm.allreduce_sum_dev(cm.user, fact.p, 4 * nt_pad, 1), "allreduce of the term facts");
+    hipLaunchKernelGGL(k_nonzero_u8, dim3(blocks(4 * nt_pad)), dim3(256), 0, s, fact.p, (uint64_t)(4 * nt_pad));
+    ps.term_flags = DevBuf<uint8_t>(pool, nt_pad);
+    hipLaunchKernelGGL(k_merge_flags, dim3(blocks(n_terms)), dim3(256), 0, s, fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad,
+                       n_terms, ps.term_flags.p);
+  }
+
   // ---- 5. class masks and vertex masks
   DevBuf<uint64_t> Pm(pool, n_terms), M(pool, n_terms);
   DX_HIP(hipMemsetAsync(Pm.p, 0, Pm.bytes() ? Pm.bytes() : 8, s));
@@ -1301,6 +1579,14 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     }
   }
   if (n_rec) hipLaunchKernelGGL(k_vertex_masks, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, O.p, kind.p, n_rec, Pm.p, M.p);
+  if (sharded && n_terms) {  // a vertex's types may be declared in another rank's part of the text
+    DevBuf<uint64_t> gathered(pool, (size_t)cm.world * n_terms);
+    const std::vector<uint64_t> counts(cm.world, n_terms);
+    DX_HIP(hipStreamSynchronize(s));
+    comm_ok(cm.allgather(cm.user, M.p, n_terms, gathered.p, counts.data(), 8), "allgather of the vertex masks");
+    hipLaunchKernelGGL(k_or_gathered, dim3(blocks(n_terms)), dim3(256), 0, s, gathered.p, cm.world, (uint64_t)n_terms, M.p);
+    DX_HIP(hipStreamSynchronize(s));
+  }
   tm.mark();
 
   // ---- 6. predicates, sort keys
@@ -1334,6 +1620,40 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   ps.n_uniq_slots = n_rec;
   if (n_rec) hipLaunchKernelGGL(k_pack_keys, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, P.p, O.p, n_rec, pred_index.p, bits_term, ps.uniq.p);
   S.reset(); P.reset(); O.reset(); kind.reset(); fact.reset();
+  if (sharded) {
+    // every triple goes to the ranks that own one of its partitions (CustomPartitioner, DAP.scala:541-551);
+    // what arrives is sorted, de-duplicated across ranks and placed like the triples of a single GPU
+    DevBuf<uint64_t> owners(pool, n_rec);
+    DevBuf<unsigned long long> counts(pool, 2 * DX_MAX_PARTITIONS);
+    DX_HIP(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * 2 * DX_MAX_PARTITIONS, s));
+    if (n_rec)
+      hipLaunchKernelGGL(k_route_count, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx,
+                         ps.term_flags.p, Pm.p, M.p, cm.world, owners.p, counts.p);
+    std::vector<unsigned long long> h(cm.world);
+    DX_HIP(hipMemcpyAsync(h.data(), counts.p, sizeof(unsigned long long) * cm.world, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    std::vector<uint64_t> send(cm.world), recv(cm.world);
+    std::vector<unsigned long long> cur(cm.world);
+    unsigned long long run = 0;
+    for (int p = 0; p < cm.world; ++p) { send[p] = h[p]; cur[p] = run; run += h[p]; }
+    if (run >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 routed triples on one GPU");
+    DX_HIP(hipMemcpyAsync(counts.p + DX_MAX_PARTITIONS, cur.data(), sizeof(unsigned long long) * cm.world, hipMemcpyHostToDevice, s));
+    DevBuf<uint64_t> outbox(pool, run);
+    if (n_rec)
+      hipLaunchKernelGGL(k_route_scatter, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, owners.p, n_rec, cm.world,
+                         counts.p + DX_MAX_PARTITIONS, outbox.p);
+    DX_HIP(hipStreamSynchronize(s));
+    DX_HIP(hipGetLastError());
+    comm_ok(cm.exchange_counts(cm.user, send.data(), recv.data()), "exchange_counts");
+    uint64_t n_in = 0;
+    for (int p = 0; p < cm.world; ++p) n_in += recv[p];
+    if (n_in >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 triples arrive on one GPU");
+    DevBuf<uint64_t> inbox(pool, n_in);
+    comm_ok(cm.exchange(cm.user, outbox.p, send.data(), inbox.p, recv.data(), 8), "exchange of the triples");
+    ps.uniq = std::move(inbox);
+    n_rec = (uint32_t)n_in;
+    ps.n_uniq_slots = n_rec;
+  }
   radix_sort_u64(pool, ps.uniq.p, nullptr, n_rec, bits_pred + 2 * bits_term, s);
   tm.mark();
 
@@ -1344,7 +1664,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemsetAsync(counters.p, 0, 16, s));
   if (n_rec)
     hipLaunchKernelGGL(k_place, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
-                       mask.p, node_flag.p, counters.p);
+                       owned, mask.p, node_flag.p, counters.p);
   tm.mark();
 
   // ---- 8. stable split by partition
@@ -1359,6 +1679,12 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   unsigned long long h_counters[2] = {0, 0};
   DX_HIP(hipMemcpyAsync(h_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
+  if (sharded) {  // placed distinct triples / edges of the whole input, each counted by one rank
+    uint64_t v[2] = {h_counters[0], h_counters[1]};
+    comm_ok(cm.allreduce_sum(cm.user, v, 2), "allreduce_sum");
+    h_counters[0] = v[0];
+    h_counters[1] = v[1];
+  }
   st.n_unique = h_counters[0];
   st.n_edges = h_counters[1];
   const uint32_t n_rows = h_part_base[nparts];
@@ -1396,6 +1722,14 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   ps.node_o = DevBuf<int64_t>(pool, n_node);
   if (n_rec) hipLaunchKernelGGL(k_node_index, dim3(blocks(n_rec)), dim3(256), 0, s, ps.uniq.p, node_flag.p, node_pos.p, n_rec, bits_term,
                                 ps.node_s.p, ps.node_o.p, ps.term_flags.p);
+  if (sharded && n_terms) {  // "this uri has a node-index row" has to hold on every rank, whoever keeps the row
+    DevBuf<uint8_t> node_bit(pool, n_terms);
+    hipLaunchKernelGGL(k_node_bit_out, dim3(blocks(n_terms)), dim3(256), 0, s, ps.term_flags.p, (uint64_t)n_terms, node_bit.p);
+    DX_HIP(hipStreamSynchronize(s));
+    comm_ok(cm.allreduce_sum_dev(cm.user, node_bit.p, n_terms, 1), "allreduce of the node flags");
+    hipLaunchKernelGGL(k_node_bit_in, dim3(blocks(n_terms)), dim3(256), 0, s, node_bit.p, (uint64_t)n_terms, ps.term_flags.p);
+    DX_HIP(hipStreamSynchronize(s));
+  }
   tm.mark();
   node_pos.reset(); node_flag.reset(); mask.reset();
 

@@ -106,7 +106,7 @@ struct dx_ctx {
   dx::DevBuf<uint8_t> qws;
   hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
   // several GPUs: collectives handed in by the host; world == 1 means single-GPU execution
-  dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr};
+  dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct dx_result {

@@ -16,11 +16,14 @@ import numpy as np
 COUNTS_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), POINTER(c_uint64))
 EXCHANGE_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, POINTER(c_uint64), c_void_p, POINTER(c_uint64), c_int)
 ALLREDUCE_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), c_int)
+ALLGATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_void_p, POINTER(c_uint64), c_int)
+ALLREDUCE_DEV_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_int)
 
 
 class DxComm(ctypes.Structure):
     _fields_ = [("rank", c_int), ("world", c_int), ("user", c_void_p), ("exchange_counts", COUNTS_FN),
-                ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN)]
+                ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN), ("allgather", ALLGATHER_FN),
+                ("allreduce_sum_dev", ALLREDUCE_DEV_FN)]
 
 
 class _DevicePointer:
@@ -53,7 +56,8 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.on_device = dist.get_backend(group) == "nccl"
-        self._fns = (COUNTS_FN(self._counts), EXCHANGE_FN(self._exchange), ALLREDUCE_FN(self._allreduce))
+        self._fns = (COUNTS_FN(self._counts), EXCHANGE_FN(self._exchange), ALLREDUCE_FN(self._allreduce),
+                     ALLGATHER_FN(self._allgather), ALLREDUCE_DEV_FN(self._allreduce_dev))
         self.struct = DxComm(self.rank, self.world, None, *self._fns)
 
     # every callback returns 0, or 1 after printing the exception: the library turns that into DX_E_IO
@@ -120,6 +124,52 @@ class TorchComm:
             for i in range(n):
                 values[i] = int(t[i])
         return self._guard(run)
+
+
+    def _allgather(self, user, send_dev, send_count, recv_dev, recv_counts, elem_bytes):
+        def run():
+            import torch
+            rc = [int(recv_counts[p]) for p in range(self.world)]
+            recv_t = device_tensor(recv_dev or 0, sum(rc), elem_bytes)
+            send_t = device_tensor(send_dev or 0, int(send_count), elem_bytes)
+            scale = recv_t.numel() // max(1, sum(rc)) if sum(rc) else 1   # odd element sizes travel as bytes
+            at = 0
+            for p in range(self.world):  # uneven sizes: one broadcast per rank, straight into its place
+                n = rc[p] * scale
+                if n:
+                    piece = recv_t[at:at + n]
+                    if p == self.rank:
+                        piece.copy_(send_t)
+                    if self.on_device:
+                        self.dist.broadcast(piece, src=self._global_rank(p), group=self.group)
+                    else:
+                        host = piece.cpu()
+                        self.dist.broadcast(host, src=self._global_rank(p), group=self.group)
+                        if p != self.rank:
+                            piece.copy_(host)
+                at += n
+            torch.cuda.synchronize()
+        return self._guard(run)
+
+    def _allreduce_dev(self, user, dev, n, elem_bytes):
+        def run():
+            import torch
+            if elem_bytes not in (1, 8):
+                raise ValueError("allreduce_sum_dev: elements of 1 or 8 bytes")
+            t = device_tensor(dev or 0, int(n), elem_bytes)
+            if not t.numel():
+                return
+            if self.on_device:
+                self.dist.all_reduce(t, group=self.group)
+            else:
+                host = t.cpu()
+                self.dist.all_reduce(host, group=self.group)
+                t.copy_(host)
+            torch.cuda.synchronize()
+        return self._guard(run)
+
+    def _global_rank(self, p):
+        return p if self.group is None else self.dist.get_global_rank(self.group, p)
 
 
 def load_tables_sharded(engine, comm: TorchComm, keys, owner) -> int:

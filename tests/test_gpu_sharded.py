@@ -42,3 +42,41 @@ def test_two_ranks_answer_like_one(tmp_path):
         spread += all(s > 0 for s in r["share_sizes"])
     assert spread >= 5  # the shuffles really spread the larger results over both ranks
     assert "remote" in res["Q2.txt"]["plan"] and "local" in res["Q2.txt"]["plan"]
+
+
+def test_two_ranks_partition_like_one(tmp_path):
+    """Each rank tokenises its half of the text; the ranks agree on one dictionary, exchange vertex facts and
+    route the triples to the owners of their partitions. Together they must hold exactly what one GPU
+    produces from the whole text, and answer the queries alike."""
+    out = tmp_path / "sharded_partition.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "sharded_partition_worker.py"), str(out)]
+    env = dict(os.environ, DX_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.load(open(out))
+    shares, alone = res["shares"], res["alone"]
+    world = len(shares)
+    assert sum(s["n_triples_in"] for s in shares) == res["n_triples"]
+    for s in shares:
+        assert s["n_terms"] == alone["n_terms"]                       # one dictionary
+        assert s["terms_head"] == shares[0]["terms_head"]             # with the same ids on every rank
+        assert (s["n_unique"], s["n_edges"], s["n_vertices"]) == (shares[0]["n_unique"], shares[0]["n_edges"], shares[0]["n_vertices"])
+    assert shares[0]["n_vertices"] == alone["n_vertices"]
+    assert shares[0]["n_edges"] <= alone["n_edges"] and shares[0]["n_unique"] <= alone["n_unique"]  # placed ones only
+    for q, want in enumerate(alone["parts"]):
+        for s in shares:
+            if s["rank"] == q % world:
+                assert s["parts"][q] == want, "partition %d" % q
+            else:
+                assert s["parts"][q] == []                           # nobody else holds it
+    merged_ni = sorted(tuple(x) for s in shares for x in s["node_index"])
+    assert merged_ni == sorted(tuple(x) for x in alone["node_index"])   # disjoint shares of the node index
+    merged_vp = sorted((k, v) for s in shares for k, v in s["vp"])
+    assert merged_vp == sorted((k, v) for k, v in alone["vp"])
+    for pname, want in alone["vp_index"].items():
+        owner = int(pname) % world
+        assert shares[owner]["vp_index"][pname] == want, pname
+    assert len(res["queries"]) == 13
+    for name, r in res["queries"].items():
+        assert r["count"] == r["want_count"] and r["columns"] == r["want_columns"] and r["rows"] == r["want_rows"], name
