@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 
-def translated_queries(engine, class_index_text, ontology):
+def translated_queries(engine, class_index_text, ontology, gather=None):
     """Host-side work that stays outside the timed path: the reference's translator turns SPARQL into
     SQL from the node index, class index and partition statistics (QueryTranslator.scala:25-119)."""
     from opus_amd import lubm
@@ -54,6 +54,15 @@ def translated_queries(engine, class_index_text, ontology):
         if tb["in_layout"]:
             k = "%05d" % tb["partition"]
             stat[k] = stat.get(k, 0) + tb["rows"]
+    if gather is not None:  # several ranks hold shares of the node index and of the partitions
+        merged_ni, merged_stat = {}, {}
+        for ni_r, stat_r in gather((ni, stat)):
+            for k, v in ni_r.items():
+                merged_ni.setdefault(k, [])
+                merged_ni[k] += [x for x in v if x not in merged_ni[k]]
+            for k, v in stat_r.items():
+                merged_stat[k] = merged_stat.get(k, 0) + v
+        ni, stat = merged_ni, merged_stat
     ci = T.load_class_index(class_index_text)
     out = {}
     for name, text in parsed.items():
@@ -177,6 +186,9 @@ def main():
     ap.add_argument("--sharded-queries", action="store_true",
                     help="extra leg for --gpus N > 1: rank 0's partitions are split over the ranks by first-level "
                          "partition and the 13 queries run on all GPUs together (hash exchange before every join)")
+    ap.add_argument("--global-partition", action="store_true",
+                    help="--gpus N > 1: the ranks partition the union of their blocks together (one dictionary, partitions "
+                         "owned by rank, triples exchanged) and answer the queries together, instead of working side by side")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
@@ -214,6 +226,17 @@ def main():
     ci = lubm.class_index_text(args.partitions, ontology)
     torch.cuda.synchronize()
     eng = Engine(local_rank)
+    together = args.global_partition and world > 1
+    comm = None
+    if together:
+        from opus_amd.host.comm import TorchComm, load_tables_sharded
+        comm = TorchComm()
+        eng.set_comm(comm)
+
+    def gather_objects(obj):
+        box = [None] * world
+        dist.all_gather_object(box, obj)
+        return box
 
     def partition():
         t0 = time.perf_counter()
@@ -221,7 +244,7 @@ def main():
         return time.perf_counter() - t0, st
 
     _, st = partition()  # sizes the allocator's cache and gives the translator its inputs
-    queries = translated_queries(eng, ci, ontology)
+    queries = translated_queries(eng, ci, ontology, gather=gather_objects if together else None)
     qnames = sorted(queries, key=lambda n: int(n[1:-4]))
     plans = {n: parse_translated(queries[n]) for n in qnames}
 
@@ -230,8 +253,12 @@ def main():
         for n in qnames:
             sql, parts = plans[n]
             eng.unload_all()                       # unloadTables of the previous query
-            for p in parts:                        # preloadTables: resident in HBM, reported as Time_load by the reference
-                eng.load_table(p)
+            if together:                           # tables stay with the rank that owns their partition
+                load_tables_sharded(eng, comm, parts, lambda q: shard.partition_owner(q, world))
+                shard.barrier(device)
+            else:
+                for p in parts:                    # preloadTables: resident in HBM, reported as Time_load by the reference
+                    eng.load_table(p)
             if first and n == qnames[0]:
                 eng.query(sql, DX_QUERY_COUNT).close()   # the reference's one untimed run of the first query
             t0 = time.perf_counter()
@@ -265,7 +292,7 @@ def main():
     red_device = device if args.backend == "nccl" else torch.device("cpu")
     elapsed, part_total, total_triples = shard.combine_timings(elapsed, sum(part_s), n_triples, red_device)
     local_counts = {n: int(counts[n]) for n in qnames}
-    counts = shard.combine_counts(local_counts, red_device)
+    counts = local_counts if together else shard.combine_counts(local_counts, red_device)  # together: already over all ranks
     sharded = sharded_query_leg(args, eng, plans, qnames, local_counts, rank, world, local_rank, barrier) if (args.sharded_queries and world > 1) else None
 
     if rank == 0:
@@ -321,7 +348,8 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "LUBM-%d per GPU (%d triples, %.2f GB of N-Triples text per GPU), %d first-level partitions, "
                                    "13 LUBM queries (Q1-Q12, Q14)" % (args.universities, n_triples, n_bytes / 1e9, args.partitions),
-                       "parallelism": "independent university blocks per GPU, no cross-GPU exchange" if world > 1 else "single GPU"},
+                       "parallelism": ("one dictionary over all ranks, first-level partitions owned by rank, triples and join inputs exchanged"
+                                       if together else "independent university blocks per GPU, no cross-GPU exchange") if world > 1 else "single GPU"},
             "partition_ms": med(part_s) * 1e3,
             "partition_stage_ms": stage_avg,
             "partition_algorithmic_GBps": hp1_alg_bytes / med(part_s) / 1e9,
