@@ -34,16 +34,28 @@ class _DevicePointer:
 
 
 def device_tensor(ptr: int, n: int, elem_bytes: int):
+    """The library's buffer as a torch tensor over the same memory. Without a GPU (the host-logic tests hand
+    in host memory) the pointer is wrapped as a CPU tensor instead."""
     import torch
     if elem_bytes == 8:
-        dtype, typestr = torch.int64, "<i8"
+        dtype, typestr, npdt = torch.int64, "<i8", np.int64
     elif elem_bytes == 4:
-        dtype, typestr = torch.int32, "<i4"
+        dtype, typestr, npdt = torch.int32, "<i4", np.int32
     else:
-        dtype, typestr, n = torch.uint8, "|u1", n * elem_bytes
+        dtype, typestr, npdt, n = torch.uint8, "|u1", np.uint8, n * elem_bytes
+    on_gpu = torch.cuda.is_available()
     if n == 0:
-        return torch.empty(0, dtype=dtype, device="cuda")
+        return torch.empty(0, dtype=dtype, device="cuda" if on_gpu else "cpu")
+    if not on_gpu:
+        raw = (ctypes.c_char * (n * np.dtype(npdt).itemsize)).from_address(ptr)
+        return torch.from_numpy(np.frombuffer(raw, dtype=npdt))
     return torch.as_tensor(_DevicePointer(ptr, n, typestr), device="cuda")
+
+
+def _sync():
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 class TorchComm:
@@ -91,7 +103,7 @@ class TorchComm:
             recv_t = device_tensor(recv_dev or 0, sum(rc) // scale, elem_bytes)
             if self.on_device:
                 self.dist.all_to_all_single(recv_t, send_t, rc, sc, group=self.group)
-                torch.cuda.synchronize()
+                _sync()
                 return
             # gloo has no all-to-all: host copies and pairwise sends (tests only)
             hs = send_t.cpu()
@@ -111,7 +123,7 @@ class TorchComm:
                 r.wait()
             if hr.numel():
                 recv_t.copy_(hr)
-            torch.cuda.synchronize()
+            _sync()
         return self._guard(run)
 
     def _allreduce(self, user, values, n):
@@ -148,7 +160,7 @@ class TorchComm:
                         if p != self.rank:
                             piece.copy_(host)
                 at += n
-            torch.cuda.synchronize()
+            _sync()
         return self._guard(run)
 
     def _allreduce_dev(self, user, dev, n, elem_bytes):
@@ -165,7 +177,7 @@ class TorchComm:
                 host = t.cpu()
                 self.dist.all_reduce(host, group=self.group)
                 t.copy_(host)
-            torch.cuda.synchronize()
+            _sync()
         return self._guard(run)
 
     def _global_rank(self, p):

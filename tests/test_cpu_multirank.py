@@ -94,3 +94,57 @@ def test_comm_callbacks_over_gloo():
         assert p.exitcode == 0
     assert got[0] == (0, [0, 100], [3, 20], 0, 2)     # recv[p] = what p addressed to me
     assert got[1] == (1, [1, 101], [3, 20], 1, 2)
+
+
+def _collectives_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+
+        import numpy as np
+        from opus_amd.host.comm import TorchComm
+        st = TorchComm().struct
+        u64 = lambda xs: (ctypes.c_uint64 * len(xs))(*xs)  # noqa: E731
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)     # noqa: E731
+        # all-to-all with counts: rank r sends r+1 elements to peer 0 and 2 elements to peer 1
+        sc = [rank + 1, 2]
+        send = np.arange(sum(sc), dtype=np.int64) + 100 * rank
+        rc_c = u64([0] * world)
+        assert st.exchange_counts(None, u64(sc), rc_c) == 0
+        rc = list(rc_c)
+        recv = np.full(sum(rc), -1, dtype=np.int64)
+        assert st.exchange(None, ptr(send), u64(sc), ptr(recv), u64(rc), 8) == 0
+        # all-gather with uneven sizes, bytes
+        mine = np.full(3 + rank, 7 + rank, dtype=np.uint8)
+        counts = [3, 4]
+        gathered = np.zeros(sum(counts), dtype=np.uint8)
+        assert st.allgather(None, ptr(mine), mine.size, ptr(gathered), u64(counts), 1) == 0
+        # sums of byte flags and of 8-byte words, in place
+        flags = np.array([1, 0, rank, 1 - rank], dtype=np.uint8)
+        words = np.array([10 + rank, 1 << 40], dtype=np.int64)
+        assert st.allreduce_sum_dev(None, ptr(flags), flags.size, 1) == 0
+        assert st.allreduce_sum_dev(None, ptr(words), words.size, 8) == 0
+        out.put((rank, rc, recv.tolist(), gathered.tolist(), flags.tolist(), words.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_data_collectives_over_gloo():
+    """All-to-all with counts, uneven all-gather and in-place sums, through the C function pointers, on host buffers."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_collectives_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, rc0, recv0, g0, f0, w0), (_, rc1, recv1, g1, f1, w1) = got
+    assert rc0 == [1, 2] and recv0 == [0, 100, 101]            # rank 0's first element, rank 1's first two
+    assert rc1 == [2, 2] and recv1 == [1, 2, 102, 103]         # what each addressed to rank 1
+    assert g0 == g1 == [7, 7, 7, 8, 8, 8, 8]
+    assert f0 == f1 == [2, 0, 1, 1]
+    assert w0 == w1 == [21, 1 << 41]
