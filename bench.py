@@ -313,14 +313,15 @@ def main():
         eng._check(eng.lib.dx_terms_bytes(eng.ctx, all_ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), all_ids.size,
                                           ctypes.byref(pool_bytes)))
         kernels = {
-            "k_tokenise (text -> 3 term spans + 64-bit hashes per record)":
-                (stage_avg["tokenise_hash"], n_bytes + 49 * n_rec),
-            "k_ht_clear + k_dict_insert (claim a 16-byte slot per term, keep the first occurrence)":
-                (stage_avg["dict_insert_kernel"], 36 * n_occ),
-            # the text once (every occurrence's own bytes), every distinct term's first bytes once, and per
-            # occurrence the span word (8), the slot index (4), the slot's representative (8), the flag (1)
-            "k_dict_verify (byte-compare every repeated occurrence with its term's first)":
-                (stage_avg["dict_verify_kernel"], n_bytes + pool_bytes.value + 21 * n_occ),
+            # one pass over the text: the text itself, per record three spans (24 B), three slot indices (12 B) and
+            # the kind (1 B) written, per occurrence its 16-byte dictionary slot read, and every distinct term's
+            # first occurrence read once more for the byte comparisons
+            "k_tokenise (text -> term spans, hashes, dictionary slots, byte comparison of repeated terms)":
+                (stage_avg["tokenise_hash"], n_bytes + (37 + 48) * n_rec + pool_bytes.value),
+            "k_ht_clear (16-byte slots)":
+                (stage_avg["dict_clear_kernel"], 16 * (1 << max(10, math.ceil(math.log2(max(1.5 * n_rec, 1)))))),
+            "k_dict_first (is this occurrence its term's first)":
+                (stage_avg["dict_first_kernel"], 29 * n_occ),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]

@@ -269,6 +269,105 @@ __device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos
   return 4 * (i + base) + sh + k;
 }
 
+// ---- dictionary slot claim, shared by the fused tokeniser and the entry-level build -----------------------
+constexpr uint32_t kMaxProbes = 1u << 14;  // a longer chain means the table is too full: the build restarts larger
+constexpr uint64_t kNoHolder = ~0ull;      // k_ht_clear's representative word: nobody has claimed the slot's term yet
+
+__device__ __forceinline__ uint64_t diff_global(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t len) {
+  uint64_t diff = 0;
+  uint64_t j = 0;
+  for (; j + 8 <= len; j += 8) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, a + j, 8); __builtin_memcpy(&y, b + j, 8);
+    diff |= x ^ y;
+  }
+  for (; j < len; ++j) diff |= (uint64_t)(a[j] ^ b[j]);
+  return diff;
+}
+
+// len bytes at window offset pos (LDS) against len bytes at b (global). The global side is requested 64 bytes at
+// a time as four independent 16-byte loads (one round trip instead of four: the loop is bound by memory
+// latency); chunks past the end are pulled back to the last 16 bytes, which compares some bytes twice and
+// never reads outside the term.
+__device__ __forceinline__ uint32_t lds_chunk_diff(const uint32_t* win, uint32_t at, const uint4& y) {
+  const uint32_t i = at >> 2, sh = at & 3;
+  const uint32_t w0 = win[i], w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
+  return (__builtin_amdgcn_alignbyte(w1, w0, sh) ^ y.x) | (__builtin_amdgcn_alignbyte(w2, w1, sh) ^ y.y) |
+         (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ y.z) | (__builtin_amdgcn_alignbyte(w4, w3, sh) ^ y.w);
+}
+__device__ __forceinline__ uint32_t diff_lds_global(const uint32_t* win, uint32_t pos, uint32_t len, const uint8_t* __restrict__ b) {
+  uint32_t diff = 0;
+  if (len >= 16) {
+    const uint32_t last = len - 16;
+    for (uint32_t j = 0; j < len; j += 64) {
+      uint32_t off[4];
+      uint4 y[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        off[c] = j + 16 * c < last ? j + 16 * c : last;
+        __builtin_memcpy(&y[c], b + off[c], 16);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) diff |= lds_chunk_diff(win, pos + off[c], y[c]);
+    }
+    return diff;
+  }
+  uint32_t i = pos >> 2;
+  const uint32_t sh = pos & 3;
+  uint32_t lo = win[i];
+  uint32_t j = 0;
+  for (; j + 4 <= len; j += 4) {
+    uint32_t y;
+    __builtin_memcpy(&y, b + j, 4);
+    const uint32_t w1 = win[i + 1];
+    diff |= __builtin_amdgcn_alignbyte(w1, lo, sh) ^ y;
+    lo = w1;
+    ++i;
+  }
+  if (j < len) {
+    const uint32_t x = __builtin_amdgcn_alignbyte(win[i + 1], lo, sh);
+    uint32_t y = 0;
+    for (uint32_t t = 0; j + t < len; ++t) y |= (uint32_t)b[j + t] << (8 * t);
+    diff |= (x ^ y) & ((1u << (8 * (len - j))) - 1u);
+  }
+  return diff;
+}
+
+// Claims or finds the slot of hash h and lowers its representative to `mine` if that is earlier in the text.
+// Returns the slot; `holder` = a representative that was in the slot before this call took effect (some other
+// occurrence that claims the same string), or kNoHolder for the very first claim. Every occurrence but that
+// first one is handed a holder and compares its bytes with it, so by induction over the order in which the
+// atomics landed all occurrences of a slot carry the same string, or a collision is reported.
+__device__ __forceinline__ uint32_t claim_slot(DictSlot* __restrict__ ht, uint64_t mask, uint64_t h, uint64_t mine, uint64_t& holder,
+                                               uint32_t* __restrict__ overflow) {
+  uint64_t slot = h & mask;
+  holder = kNoHolder;
+  for (uint32_t probes = 0; probes < kMaxProbes; ++probes) {
+    // key and representative share one 16-byte slot: one load answers "is this my slot" and "am I earlier"
+    const uint4 sv = *reinterpret_cast<const uint4*>(&ht[slot]);
+    uint64_t cur = ((uint64_t)sv.y << 32) | sv.x;
+    if (cur == 0) {
+      cur = atomicCAS((unsigned long long*)&ht[slot].key, 0ull, (unsigned long long)h);
+      if (cur == 0 || cur == h) {
+        holder = atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+        return (uint32_t)slot;
+      }
+    } else if (cur == h) {
+      const uint64_t r = ((uint64_t)sv.w << 32) | sv.z;
+      if (r == kNoHolder) {  // claimed a moment ago, representative not published yet: the atomic's answer decides
+        holder = atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+      } else {               // any published representative serves as holder; lowering it needs no answer
+        holder = r;
+        if (r > mine) atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+      }
+      return (uint32_t)slot;
+    }
+    slot = (slot + 1) & mask;
+  }
+  *overflow = 1;
+  return 0;
+}
+
 // Stages [tile0 - TK_PRE, tile0 + TK_WIN) of the text into `win`, clipped to the text; bytes outside it and
 // the eight padding words after the window read as '\n'. Ends with a block barrier.
 // LDS-DMA: every wave-instruction moves 64 x 16 contiguous bytes straight into the window (no VGPR staging,
@@ -307,7 +406,9 @@ __device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __res
 __global__ void __launch_bounds__(TK_THREADS)
 k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask,
            const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash, uint64_t n_rec,
-           uint64_t* __restrict__ t_rep /*[field][record]: (offset << 24) | length*/, uint64_t* __restrict__ t_hash /*[field][record]*/, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
+           DictSlot* __restrict__ ht, uint64_t ht_mask, uint64_t* __restrict__ t_rep /*[field][record]: (offset << 24) | length*/,
+           uint32_t* __restrict__ t_slot /*[field][record]*/, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err,
+           uint32_t* __restrict__ coll /*[0] two strings with one hash, [1] table too full*/) {
   __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 8];
   __shared__ uint16_t starts[TK_STARTS];
   __shared__ uint32_t scan_lds[8];
@@ -336,7 +437,7 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       if (threadIdx.x == 0) atomicMin(err, (unsigned long long)tile0);
       for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
         const uint64_t r = (uint64_t)first_rec + lr;
-        for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_hash[k * n_rec + r] = 1; }
+        for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_slot[k * n_rec + r] = 0; }
         kind[r] = 0;
       }
       return;
@@ -466,20 +567,74 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       out.kind = kd;
     }
     const uint64_t r = (uint64_t)first_rec + lr;
+    uint32_t slot[3] = {0, 0, 0};
     if (out.bad) {
       atomicMin(err, (unsigned long long)gstart);
-      for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 1; }
+      for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 0; }  // 0 is no term's hash
       out.kind = 0;
     }
-    for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = out.rep[k]; t_hash[k * n_rec + r] = out.hash[k]; }  // field-major: coalesced
+    // Dictionary: claim the three terms' slots, and compare each term with the occurrence that held its slot
+    // before (its own bytes are still in LDS; the holder's are somewhere else in the text).
+    // A few terms (predicates, classes, a subject's run of records) fill a wave many times over. Their lanes
+    // would all hit one slot, with atomics while the tiles in flight race for the earliest occurrence, and the
+    // L2 carries such atomics out one lane at a time: a bounded number of rounds folds the most frequent
+    // hashes of the wave onto their first lane (the earliest in the text), whose occurrence then stands in
+    // as the holder for the others.
+    const int lane = threadIdx.x & 63;
+    const bool valid = !out.bad;
+    uint64_t holder[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint64_t h = out.hash[k];
+      int leader = -1;
+      uint64_t todo = __ballot(valid);
+#pragma unroll 1
+      for (int round = 0; round < 4 && todo; ++round) {
+        const int l = __ffsll((long long)todo) - 1;
+        const uint64_t hl = __shfl(h, l, 64);
+        const bool same = valid && h == hl;
+        if (same && lane != l) leader = l;
+        todo &= ~__ballot(same);
+      }
+      holder[k] = kNoHolder;
+      if (valid && leader < 0) {
+        // the usual case (the term is known) is answered by one load; lowering the representative needs no answer
+        const uint4 sv = *reinterpret_cast<const uint4*>(&ht[h & ht_mask]);
+        const uint64_t key = ((uint64_t)sv.y << 32) | sv.x, val = ((uint64_t)sv.w << 32) | sv.z;
+        if (key == h && val != kNoHolder) {
+          slot[k] = (uint32_t)(h & ht_mask);
+          holder[k] = val;
+          if (val > out.rep[k]) atomicMin((unsigned long long*)&ht[h & ht_mask].val, (unsigned long long)out.rep[k]);
+        } else {
+          slot[k] = claim_slot(ht, ht_mask, h, out.rep[k], holder[k], coll + 1);
+        }
+      }
+      const int src = leader >= 0 ? leader : lane;
+      const uint32_t slot_l = __shfl(slot[k], src, 64);
+      const uint64_t rep_l = __shfl(out.rep[k], src, 64);
+      if (leader >= 0) { slot[k] = slot_l; holder[k] = rep_l; }
+    }
+    if (valid) {
+      bool differ = false;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (holder[k] == kNoHolder || holder[k] == out.rep[k]) continue;
+        const uint64_t len = out.rep[k] & ((1ull << kRepLenBits) - 1);
+        if (len != (holder[k] & ((1ull << kRepLenBits) - 1))) { differ = true; continue; }
+        const uint64_t own = out.rep[k] >> kRepLenBits;
+        const uint8_t* hb = text + (holder[k] >> kRepLenBits);
+        if (own >= tile0 && own + len <= tile0 + win_bytes) differ |= diff_lds_global(win, (uint32_t)(own - tile0) + TK_PRE, (uint32_t)len, hb) != 0;
+        else differ |= diff_global(text + own, hb, len) != 0;  // a record that ran past the staged window
+      }
+      if (differ) coll[0] = 1;
+    }
+    for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = out.rep[k]; t_slot[k * n_rec + r] = slot[k]; }  // field-major: coalesced
     kind[r] = out.kind;
   }
   }
 }
 
 // ---- 3. dictionary ---------------------------------------------------------------------------------
-constexpr uint32_t kMaxProbes = 1u << 14;  // a longer chain means the table is too full: the build restarts larger
-
 __global__ void __launch_bounds__(256) k_ht_clear(DictSlot* __restrict__ ht, uint64_t cap) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
     *reinterpret_cast<uint4*>(&ht[i]) = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -500,27 +655,10 @@ k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ 
   const uint64_t h = valid ? t_hash[i] : 0, mine = valid ? t_rep[i] : ~0ull;
   const uint64_t h_left = __shfl_up(h, 1, 64);
   const bool leader = valid && (lane == 0 || h_left != h);
-  uint64_t slot = h & mask;
+  uint64_t slot = 0;
   if (leader) {
-    uint32_t probes = 0;
-    for (; probes < kMaxProbes; ++probes) {
-      // key and representative share one 16-byte slot: one load answers "is this my slot" and "am I earlier"
-      const uint4 sv = *reinterpret_cast<const uint4*>(&ht[slot]);
-      uint64_t cur = ((uint64_t)sv.y << 32) | sv.x;
-      if (cur == 0) {
-        cur = atomicCAS((unsigned long long*)&ht[slot].key, 0ull, (unsigned long long)h);
-        if (cur == 0 || cur == h) {
-          atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
-          break;
-        }
-      } else if (cur == h) {
-        const uint64_t r = ((uint64_t)sv.w << 32) | sv.z;
-        if (r > mine) atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
-        break;
-      }
-      slot = (slot + 1) & mask;
-    }
-    if (probes == kMaxProbes) { *overflow = 1; slot = 0; }
+    uint64_t holder;
+    slot = claim_slot(ht, mask, h, mine, holder, overflow);
   }
   const uint64_t leaders = __ballot(leader);
   const uint64_t at_or_below = leaders & (~0ull >> (63 - lane));
@@ -529,92 +667,12 @@ k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ 
   if (valid) t_slot[i] = run_slot;
 }
 
-// first[i] = 1 when occurrence i is its slot's representative; any occurrence whose bytes differ from
-// the representative's proves a 64-bit collision between different strings.
-// The kernel walks the text the way the tokeniser does: one block per tile, the tile staged into LDS with
-// wide coalesced copies, one thread per record. An occurrence's own bytes are then read from LDS a word
-// at a time; only the representative's bytes (somewhere earlier in the text, mostly cache-resident for
-// frequent terms) come from global memory. Reading the own bytes lane by lane from global memory instead
-// costs more than the rest of the kernel together.
-__device__ __forceinline__ uint64_t diff_global(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t len) {
-  uint64_t diff = 0;
-  uint64_t j = 0;
-  for (; j + 8 <= len; j += 8) {
-    uint64_t x, y;
-    __builtin_memcpy(&x, a + j, 8); __builtin_memcpy(&y, b + j, 8);
-    diff |= x ^ y;
-  }
-  for (; j < len; ++j) diff |= (uint64_t)(a[j] ^ b[j]);
-  return diff;
-}
-
-__global__ void __launch_bounds__(TK_THREADS)
-k_dict_verify(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_first, const uint64_t* __restrict__ t_rep,
-              const uint32_t* __restrict__ t_slot, uint64_t n_rec, const DictSlot* __restrict__ ht, uint8_t* __restrict__ first,
-              uint32_t* __restrict__ collision) {
-  __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 8];
-  const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
-  const uint32_t first_rec = tile_first[blockIdx.x];
-  const uint32_t n_here = tile_first[blockIdx.x + 1] - first_rec;
-  if (n_here == 0) return;  // block-uniform
-  stage_window(win, text, n, tile0);
-  const uint64_t avail = n - tile0;
-  const uint64_t win_end = tile0 + (avail < (uint64_t)TK_WIN ? avail : (uint64_t)TK_WIN);  // text offset one past the window
-  const uint64_t len_mask = (1ull << kRepLenBits) - 1;
-  bool bad = false;
-  for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
-    const uint64_t rec = (uint64_t)first_rec + lr;
-    uint64_t mine[3], rep[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mine[k] = t_rep[k * n_rec + rec];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) rep[k] = ht[t_slot[k * n_rec + rec]].val;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const bool is_first = mine[k] == rep[k];
-      first[k * n_rec + rec] = is_first;
-      if (is_first) continue;
-      const uint64_t len = mine[k] & len_mask;
-      if (len != (rep[k] & len_mask)) { bad = true; continue; }
-      const uint64_t own = mine[k] >> kRepLenBits;
-      const uint8_t* b = text + (rep[k] >> kRepLenBits);
-      if (own < tile0 || own + len > win_end) {  // a record the tokeniser took out of the window as well
-        bad |= diff_global(text + own, b, len) != 0;
-        continue;
-      }
-      const uint32_t pos = (uint32_t)(own - tile0) + TK_PRE;
-      uint32_t diff = 0;
-      uint32_t i = pos >> 2;
-      const uint32_t sh = pos & 3;
-      uint32_t lo = win[i];
-      uint32_t j = 0;
-      for (; j + 16 <= len; j += 16) {  // 16 representative bytes per global load against 5 LDS words
-        uint4 y;
-        __builtin_memcpy(&y, b + j, 16);
-        const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
-        diff |= (__builtin_amdgcn_alignbyte(w1, lo, sh) ^ y.x) | (__builtin_amdgcn_alignbyte(w2, w1, sh) ^ y.y) |
-                (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ y.z) | (__builtin_amdgcn_alignbyte(w4, w3, sh) ^ y.w);
-        lo = w4;
-        i += 4;
-      }
-      for (; j + 4 <= len; j += 4) {
-        uint32_t y;
-        __builtin_memcpy(&y, b + j, 4);
-        const uint32_t w1 = win[i + 1];
-        diff |= __builtin_amdgcn_alignbyte(w1, lo, sh) ^ y;
-        lo = w1;
-        ++i;
-      }
-      if (j < len) {
-        const uint32_t x = __builtin_amdgcn_alignbyte(win[i + 1], lo, sh);
-        uint32_t y = 0;
-        for (uint32_t t = 0; j + t < len; ++t) y |= (uint32_t)b[j + t] << (8 * t);
-        diff |= (x ^ y) & ((1u << (8 * (uint32_t)(len - j))) - 1u);
-      }
-      bad |= diff != 0;
-    }
-  }
-  if (bad) *collision = 1;
+// first[i] = 1 when occurrence i is its slot's representative (the earliest occurrence of its term in the text)
+__global__ void __launch_bounds__(256)
+k_dict_first(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot, uint64_t n_occ, const DictSlot* __restrict__ ht,
+             uint8_t* __restrict__ first) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_occ) first[i] = t_rep[i] == ht[t_slot[i]].val;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1174,7 +1232,7 @@ struct StageTimer {
 
 // Stages 10 and 11 are the two big kernels inside "dictionary", timed on their own.
 const char* const kStageNames[12] = {"line_scan", "tokenise_hash", "dictionary", "string_pool", "vertex_masks", "sort_triples",
-                                     "place", "split_partitions", "node_index", "vp_index", "dict_insert_kernel", "dict_verify_kernel"};
+                                     "place", "split_partitions", "node_index", "vp_index", "dict_clear_kernel", "dict_first_kernel"};
 
 void dict_build_table(dx_ctx* ctx) {
   Dictionary& d = ctx->dict;
@@ -1425,10 +1483,10 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
 
   const uint64_t n_occ = 3ull * n_rec;
   if (n_occ >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32/3 records on one GPU");
-  DevBuf<uint64_t> t_rep(pool, n_occ), t_hash(pool, n_occ);
+  DevBuf<uint64_t> t_rep(pool, n_occ);
   DevBuf<uint8_t> kind(pool, n_rec);
   DevBuf<uint32_t> t_slot(pool, n_occ);
-  // Table capacity: 1.5 slots per record to start with (LUBM-like data has ~0.55 distinct terms per
+  // Table capacity: 1.5 slots per record to start with (LUBM-like data has ~0.3 distinct terms per
   // record); a probe chain that runs too long reports overflow and the build restarts twice as large.
   // 4 slots per record can never overflow (at most 3 distinct terms per record).
   uint64_t cap = 1024;
@@ -1439,25 +1497,21 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint32_t> coll(pool, 2);  // [0] true hash collision, [1] table overflow
   uint64_t seed = 0x243F6A8885A308D3ull;
   uint32_t n_terms = 0;
-  float ms_tok = 0, ms_insert = 0, ms_verify = 0;
-  bool tokenised = false;
+  float ms_tok = 0, ms_clear = 0, ms_first = 0;
   for (int attempt = 0;; ++attempt) {
     hipEvent_t e0, e1, e2, e3;
     DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2)); DX_HIP(hipEventCreate(&e3));
-    // ---- 2. tokenise + hash (again only when the seed changed)
+    // ---- 2./3. tokenise + hash + dictionary slots + byte comparison, in one pass over the text
     DX_HIP(hipEventRecord(e0, s));
-    if (n_rec && !tokenised)
-      hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed,
-                         hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec, t_rep.p,
-                         t_hash.p, kind.p, err.p);
-    DX_HIP(hipEventRecord(e1, s));
-    // ---- 3. dictionary
     hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
     DX_HIP(hipMemsetAsync(coll.p, 0, 8, s));
-    if (n_occ) hipLaunchKernelGGL(k_dict_insert, dim3(blocks(n_occ)), dim3(256), 0, s, t_hash.p, t_rep.p, n_occ, ht.p, cap - 1, t_slot.p, coll.p + 1);
+    DX_HIP(hipEventRecord(e1, s));
+    if (n_rec)
+      hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed,
+                         hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec,
+                         ht.p, cap - 1, t_rep.p, t_slot.p, kind.p, err.p, coll.p);
     DX_HIP(hipEventRecord(e2, s));
-    if (n_occ) hipLaunchKernelGGL(k_dict_verify, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, tile_counts.p, t_rep.p, t_slot.p, (uint64_t)n_rec,
-                                  ht.p, first.p, coll.p);
+    if (n_occ) hipLaunchKernelGGL(k_dict_first, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, n_occ, ht.p, first.p);
     DX_HIP(hipEventRecord(e3, s));
     exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
     unsigned long long h_err = ~0ull;
@@ -1466,11 +1520,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipMemcpyAsync(h_coll, coll.p, 8, hipMemcpyDeviceToHost, s));
     DX_HIP(hipMemcpyAsync(&n_terms, d_total.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
-    float a = 0, b = 0, c = 0;
-    DX_HIP(hipEventElapsedTime(&a, e0, e1)); DX_HIP(hipEventElapsedTime(&b, e1, e2)); DX_HIP(hipEventElapsedTime(&c, e2, e3));
-    if (!tokenised) ms_tok = a;
-    ms_insert = b; ms_verify = c;
-    tokenised = true;
+    DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_first, e2, e3));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
@@ -1485,7 +1535,6 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     if (st.hash_retries >= 7) throw DxError(DX_E_RANGE, "dictionary: hash collisions persisted over 8 seeds");
     seed = mix64(seed + 0x9E3779B97F4A7C15ull);
     ++st.hash_retries;
-    tokenised = false;
   }
   st.n_terms = n_terms;
   Dictionary& d = ctx->dict;
@@ -1512,7 +1561,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   d.ht = std::move(ht);
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
-  t_hash.reset(); t_slot.reset(); first.reset(); first_scan.reset();
+  t_slot.reset(); first.reset(); first_scan.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
@@ -1847,8 +1896,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   float total = 0;
   DX_HIP(hipEventElapsedTime(&total, tm.ev.front(), tm.ev.back()));
   st.ms_total = total;
-  st.ms_stage[10] = ms_insert;
-  st.ms_stage[11] = ms_verify;
+  st.ms_stage[10] = ms_clear;
+  st.ms_stage[11] = ms_first;
   ps.valid = true;
 }
 

@@ -127,3 +127,34 @@ def test_random_small_graphs(engine):
         ci = "".join("<C%d>\t%s\n" % (c, ",".join(str(x) for x in sorted(set(rng.integers(0, nparts, size=rng.integers(1, 3)).tolist()))))
                      for c in range(ncls - 1))  # the last class is not indexed
         _run(engine, "\n".join(lines) + "\n", ci, nparts)
+
+
+def _term_hash(bs: bytes, seed: int) -> int:
+    """The library's 64-bit term hash (TermHash in opus_amd/csrc/dx_device.h), restated to build a collision."""
+    m = 0xFFFFFFFF
+    rotl = lambda x, r: ((x << r) | (x >> (32 - r))) & m  # noqa: E731
+    a, b = 0x9747B28C ^ (seed & m), 0x85EBCA6B ^ (seed >> 32)
+    for i in range(0, len(bs), 4):
+        k = int.from_bytes(bs[i:i + 4].ljust(4, b"\0"), "little")
+        x = (rotl(a ^ ((k * 0xCC9E2D51) & m), 15) * 5 + 0xE6546B64) & m
+        a, b = b ^ x, x
+    h = ((a << 32) | (b ^ len(bs))) & ((1 << 64) - 1)
+    for c in (0xFF51AFD7ED558CCD, 0xC4CEB9FE1A85EC53):
+        h ^= h >> 33
+        h = (h * c) & ((1 << 64) - 1)
+    h ^= h >> 33
+    return h or 1
+
+
+def test_true_hash_collision_is_detected_and_resolved(engine):
+    """Two different terms with the same 64-bit hash under the first seed (constructed from the hash's algebra):
+    the byte comparison must notice, and the build must start over with another seed and still be exact."""
+    s1, s2 = "x?'uZsx5J<MG", "Ybabp)p>`j;p"
+    seed0 = 0x243F6A8885A308D3
+    assert s1 != s2 and _term_hash(s1.encode(), seed0) == _term_hash(s2.encode(), seed0)
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    text = ("%s %s <A> .\n%s %s <B> .\n%s <p> %s .\n%s <q> \"lit\" .\n<c> <p> %s .\n<c> %s <A> .\n" %
+            (s1, T, s2, T, s1, s2, s2, s1, T))
+    st, got, ref = _run(engine, text, "<A>\t0\n<B>\t1\n", 2)
+    assert st.hash_retries >= 1
+    assert s1 in got["strs"] and s2 in got["strs"]
