@@ -476,6 +476,10 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     TermHash hs(seed), hp(seed), ho(seed);
     b[0] = p0;
     e[0] = scan_token(win, p0, hs);
+    // The home slots of subject and predicate are requested as soon as their hashes are known: the answers
+    // travel while the rest of the line is scanned in LDS (subject and predicate are never trimmed further).
+    const uint64_t h_early0 = hs.finish(e[0] - b[0]);
+    const uint4 sv_early0 = *reinterpret_cast<const uint4*>(&ht[h_early0 & ht_mask]);
     uint32_t p = e[0];
     odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
     ++p;
@@ -485,6 +489,8 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     }
     b[1] = p;
     e[1] = scan_token(win, p, hp);
+    const uint64_t h_early1 = hp.finish(e[1] - b[1]);
+    const uint4 sv_early1 = *reinterpret_cast<const uint4*>(&ht[h_early1 & ht_mask]);
     p = e[1];
     odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
     ++p;
@@ -550,8 +556,8 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
         if (q < e[2]) ho.add_word(__builtin_amdgcn_alignbyte(win[i + 1], lo, sh) & ((1u << (8 * (e[2] - q))) - 1u));
       }
       const uint32_t len[3] = {e[0] - b[0], e[1] - b[1], e[2] - b[2]};
-      out.hash[0] = hs.finish(len[0]);
-      out.hash[1] = hp.finish(len[1]);
+      out.hash[0] = h_early0;
+      out.hash[1] = h_early1;
       out.hash[2] = ho.finish(len[2]);
       for (int k = 0; k < 3; ++k) out.rep[k] = ((tile0 + (b[k] - TK_PRE)) << kRepLenBits) | len[k];
       uint8_t kd = 0;
@@ -599,7 +605,10 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       holder[k] = kNoHolder;
       if (valid && leader < 0) {
         // the usual case (the term is known) is answered by one load; lowering the representative needs no answer
-        const uint4 sv = *reinterpret_cast<const uint4*>(&ht[h & ht_mask]);
+        uint4 sv;
+        if (k == 0 && !odd) sv = sv_early0;
+        else if (k == 1 && !odd) sv = sv_early1;
+        else sv = *reinterpret_cast<const uint4*>(&ht[h & ht_mask]);
         const uint64_t key = ((uint64_t)sv.y << 32) | sv.x, val = ((uint64_t)sv.w << 32) | sv.z;
         if (key == h && val != kNoHolder) {
           slot[k] = (uint32_t)(h & ht_mask);
