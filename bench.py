@@ -336,7 +336,8 @@ def main():
             names = [w for w in dom.replace("+", " ").split() if w.startswith("k_")]
             if names and all(nm in pmc for nm in names):
                 traffic = sum(pmc[nm]["bytes"] for nm in names)
-        # algorithmic bytes of the whole partitioner per SURVEY 8(d): text once + R*(24+16) B per triple
+        # algorithmic bytes of the whole partitioner: the text once + R * (24 + 16) B per triple (R = replication:
+        # 24 B per row of a first-level partition, 16 B per row of a vertical-partition table)
         R = st.n_rows / max(1, st.n_triples)
         hp1_alg_bytes = n_bytes + st.n_rows * 40
         out = {

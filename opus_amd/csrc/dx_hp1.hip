@@ -1311,7 +1311,7 @@ static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514 
 
 // Distinct values of the two columns of a table (load time, untimed by the reference as well: it is part
 // of caching the table, QueryProcessor.scala:222-232). Subjects are counted on the stored order when the
-// table is one sorted slice, otherwise both columns go through a radix sort of a copy.
+// table is one sorted slice; any other column is counted through a byte per term.
 __global__ void __launch_bounds__(256)
 k_count_changes(const uint64_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ out) {
   __shared__ uint32_t lds[8];
@@ -1323,24 +1323,45 @@ k_count_changes(const uint64_t* __restrict__ v, uint64_t n, unsigned long long* 
   if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
 }
 
+// Distinct values of a column without sorting it: one byte per term, set by plain stores (every writer stores
+// the same value, so no atomics and no lane-by-lane traffic on the bytes of frequent terms), then counted.
+__global__ void __launch_bounds__(256)
+k_mark_terms(const int64_t* __restrict__ col, uint64_t n, uint64_t n_terms, uint8_t* __restrict__ seen) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t v = (uint64_t)col[i];
+    if (v < n_terms && !seen[v]) seen[v] = 1;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_count_marked(const uint8_t* __restrict__ seen, uint64_t n_terms, unsigned long long* __restrict__ out) {
+  __shared__ uint32_t lds[8];
+  uint32_t c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_terms; i += (uint64_t)gridDim.x * blockDim.x) c += seen[i] ? 1u : 0u;
+  uint32_t total;
+  (void)block_excl_scan_256<uint32_t>(c, lds, total);
+  if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
+}
+
 void table_statistics(dx_ctx* ctx, CatalogTable& t) {
   hipStream_t s = ctx->stream;
   if (t.rows == 0) { t.distinct_s = t.distinct_o = 0; return; }
+  if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
+  const uint64_t n_terms = ctx->dict.n_terms;
   DevBuf<unsigned long long> cnt(ctx->pool, 2);
   DX_HIP(hipMemsetAsync(cnt.p, 0, 16, s));
-  const int bits = ctx->dict.valid() ? bits_for(ctx->dict.n_terms ? ctx->dict.n_terms : 1) : 64;
   const unsigned g = (unsigned)std::min<uint64_t>(2048, (t.rows + 255) / 256);
-  DevBuf<uint64_t> tmp(ctx->pool, t.rows);
-  const bool sorted_s = t.slices.size() <= 1;
+  const bool sorted_s = t.slices.size() == 1;  // one slice of a partition: rows are in (s, o) order
+  DevBuf<uint8_t> seen(ctx->pool, n_terms ? n_terms : 1);
   for (int col = 0; col < 2; ++col) {
     const int64_t* src = col == 0 ? t.s : t.o;
-    const uint64_t* keys = (const uint64_t*)src;
-    if (!(col == 0 && sorted_s)) {
-      DX_HIP(hipMemcpyAsync(tmp.p, src, t.rows * 8, hipMemcpyDeviceToDevice, s));
-      radix_sort_u64(ctx->pool, tmp.p, nullptr, t.rows, bits, s);
-      keys = tmp.p;
+    if (col == 0 && sorted_s) {
+      hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, (const uint64_t*)src, t.rows, cnt.p + col);
+      continue;
     }
-    hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, keys, t.rows, cnt.p + col);
+    DX_HIP(hipMemsetAsync(seen.p, 0, n_terms ? n_terms : 1, s));
+    hipLaunchKernelGGL(k_mark_terms, dim3(g), dim3(256), 0, s, src, t.rows, n_terms, seen.p);
+    hipLaunchKernelGGL(k_count_marked, dim3((unsigned)std::min<uint64_t>(1024, (n_terms + 255) / 256 ? (n_terms + 255) / 256 : 1)), dim3(256), 0, s,
+                       seen.p, n_terms, cnt.p + col);
   }
   unsigned long long h[2] = {0, 0};
   DX_HIP(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, s));

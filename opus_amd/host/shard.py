@@ -1,9 +1,9 @@
 """Host-side logic of a multi-GPU run: which rank takes which block of the input, and how the ranks'
 measurements combine. One process per GPU (torch.distributed: RCCL on GPUs, gloo in CPU tests).
 
-Round-1 sharding: the synthetic LUBM input is cut by university; rank r owns universities
-[r*U, (r+1)*U) and runs both hot paths on its block with no exchange. The functions here are the
-whole N>1 host path, so that CPU tests with gloo cover it.
+Input sharding: the synthetic LUBM input is cut by university; rank r generates universities
+[r*U, (r+1)*U). What the ranks do with their blocks (side by side, or one partitioning of the union with
+exchanges) is decided by the caller; the functions here are host logic that CPU tests cover with gloo.
 """
 from __future__ import annotations
 

@@ -11,7 +11,7 @@ inner joins, equality on strings, bag semantics, UNION as set union -- the part
 of SQL both engines agree on.
 
 PARITY UNPINNED: the reference holds no expected counts or bindings for any
-query (SURVEY of its tests: one `assertTrue(true)`); results are checked against
+query (its only test is one `assertTrue(true)`, AppTest.scala:13-16); results are checked against
 this restatement only.
 """
 from __future__ import annotations

@@ -78,6 +78,9 @@ EDGE_CASES = {
         "<a> <p> \n <s> <o> .\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n", "<A>\t0\n", 1),
     # far more records per 32 KiB of text than an ordinary tile holds
     "dense_short_lines": ("".join("s%d p o%d .\n" % (i % 700, i % 13) for i in range(12000)) + "s1 a A .\n", "A\t0\n", 1),
+    # three new terms per record: more terms than the dictionary table's first size has slots, so it regrows
+    "all_terms_distinct": ("".join("<s%d> <p%d> <o%d> .\n" % (i, i, i) for i in range(3000)) +
+                           "<s1> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n", "<A>\t0,1\n", 2),
     "empty_input": ("", "<A>\t0\n", 2),
     "only_comments": ("# nothing\n# here\n", "<A>\t0\n", 2),
 }
