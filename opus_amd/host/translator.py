@@ -204,11 +204,15 @@ def table_name(partition: str) -> str:
     return partition.replace("-", "_").replace("=", "_E_").strip()
 
 
-def build_query_index(pq: ParsedQuery, node_types: Callable[[str], list], class_index: dict, statistics: dict):
-    """QueryTranslator.scala:126-241 for bound predicates. `node_types(uri)`
-    returns the distinct classes of uri in the node index. Returns
-    {tp id: [partition-_3=pred]} in the reference's iteration order, or None when
-    some triple pattern cannot be placed (the reference prints 'cannot be indexed')."""
+def build_query_index(pq: ParsedQuery, node_types: Callable[[str], list], class_index: dict, statistics: dict,
+                      sub_parts: Callable[[str, str], list] | None = None):
+    """QueryTranslator.buildQueryIndex + mapSubPartitions (QueryTranslator.scala:126-241). `node_types(uri)`
+    returns the distinct classes of uri in the node index; `sub_parts(partition, uri)` the entries of uri in
+    that partition's VP index ("s<dir>" / "o<dir>", the `parts` column of classSubPart_index split at commas),
+    which only triple patterns with a variable predicate need (the reference has the loading of that index
+    commented out, :47-57, so there such patterns fail; here they work when the index is handed in). Returns
+    {tp id: [partition-_3=pred, ...]} in the reference's iteration order, or None when some triple pattern
+    cannot be placed (the reference prints 'cannot be indexed')."""
     order = _int_order(list(pq.mappings))
     index = {}
     for tp_id in order:
@@ -240,9 +244,18 @@ def build_query_index(pq: ParsedQuery, node_types: Callable[[str], list], class_
     for tp_id in scala_immutable_order(list(index), lambda k: k):
         s, p, o = tps[tp_id]
         if is_variable(p):
-            raise NotImplementedError(
-                "variable-predicate triple patterns need the per-partition VP index, whose loading the "
-                "reference has commented out (QueryTranslator.scala:47-57)")
+            if sub_parts is None:
+                raise NotImplementedError(
+                    "variable-predicate triple patterns need the per-partition VP index, whose loading the "
+                    "reference has commented out (QueryTranslator.scala:47-57)")
+            part = index[tp_id]
+            if not is_variable(s):      # :195-209
+                out[tp_id] = [part + "-_3=" + uri_to_storage(e[1:]) for e in sub_parts(part, s) if e[:1] == "s"]
+            elif not is_variable(o) and not is_literal(o):   # :210-224
+                out[tp_id] = [part + "-_3=" + uri_to_storage(e[1:]) for e in sub_parts(part, o) if e[:1] == "o"]
+            else:
+                out[tp_id] = [part]     # :227-229
+            continue
         out[tp_id] = [index[tp_id] + "-_3=" + uri_to_storage(p)]
     return {k: out[k] for k in scala_immutable_order(list(out), lambda k: k)}
 
@@ -277,6 +290,30 @@ def translate_sub(partition: str, tp) -> str:
     return _single_var(partition, tp) if n == 1 else _double_var(partition, tp) if n == 2 else _three_var(partition, tp)
 
 
+def translate_sub_union(partitions: list, tp) -> str:
+    """The Array[String] overloads (QueryTranslator.scala:466-542): one UNION arm per sub-partition, the
+    variable predicate bound to the constant '<' + partition key + '>'. The overloads' other branches
+    interpolate the array itself into the SQL text (a JVM object name), which no engine can run."""
+    s, p, o = tp
+    n = sum(1 for x in tp if "?" in x)
+    if not partitions:
+        raise NotImplementedError("variable predicate without any sub-partition: the reference emits ' )'")
+    tab = lambda key: "table" + table_name(key)  # noqa: E731
+    if n == 1 and "?" in p:
+        v = remove_non_alnum(p)
+        q = "( " + "".join(" (SELECT '<%s>' AS %s FROM %s WHERE s == '%s' AND o == '%s') UNION" % (k, v, tab(k), s, o) for k in partitions)
+        return q[:-5] + " )"
+    if n == 2 and "?" in s and "?" in p:
+        v1, v2 = remove_non_alnum(s), remove_non_alnum(p)
+        q = "( " + "".join("(SELECT s AS %s, '<%s>' AS %s FROM %s WHERE o == '%s')UNION" % (v1, k, v2, tab(k), o) for k in partitions)
+        return q[:-5] + " )"
+    if n == 2 and "?" in p and "?" in o:
+        v1, v2 = remove_non_alnum(p), remove_non_alnum(o)
+        q = "( " + "".join("(SELECT o AS %s, '<%s>' AS %s FROM %s WHERE s == '%s')UNION" % (v2, k, v1, tab(k), s) for k in partitions)
+        return q[:-5] + " )"
+    raise NotImplementedError("variable predicate with this combination of variables: the reference prints a JVM array name")
+
+
 def _var_table_mappings(sub: str, table: str) -> dict:
     vars_ = sub[sub.index("SELECT") + 6: sub.index("FROM")]
     out = {}
@@ -301,10 +338,11 @@ def translate_tp(pq: ParsedQuery, query_index: dict) -> str:
     for v in visit:
         for i in aggr[v]:
             tp = tps[i]
-            if is_variable(tp[1]):
-                raise NotImplementedError("variable predicate")
             tab = "tab%d" % i
-            sub = translate_sub("table" + table_name(query_index[i][0]), tp) + " AS " + tab
+            if is_variable(tp[1]):
+                sub = translate_sub_union(query_index[i], tp) + " AS " + tab
+            else:
+                sub = translate_sub("table" + table_name(query_index[i][0]), tp) + " AS " + tab
             join_tables.setdefault(v, []).append(tab)
             if i not in used:
                 var_table.update(_var_table_mappings(sub, tab))
@@ -329,13 +367,13 @@ def translate_tp(pq: ParsedQuery, query_index: dict) -> str:
     return q
 
 
-def translate_query(name: str, sparql_text: str, node_types, class_index: dict, statistics: dict):
+def translate_query(name: str, sparql_text: str, node_types, class_index: dict, statistics: dict, sub_parts=None):
     """Returns the text of translated_queries_N_bal/<name>, or None when the query
     cannot be indexed (QueryTranslator.scala:92-114)."""
     pq = ParsedQuery(sparql_text)
     if not pq.is_indexed:
         return None
-    qi = build_query_index(pq, node_types, class_index, statistics)
+    qi = build_query_index(pq, node_types, class_index, statistics, sub_parts)
     if qi is None:
         return None
     sql = translate_tp(pq, qi)

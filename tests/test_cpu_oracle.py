@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -152,3 +153,39 @@ def test_product_code_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.replace("the oracle", ""), os.path.join(dirpath, f)
+
+
+def test_translator_variable_predicate_union():
+    """QueryTranslator.mapSubPartitions + the Array[String] templates (QueryTranslator.scala:189-241, 500-533):
+    a variable predicate with a constant subject becomes one UNION arm per 's' entry of the VP index."""
+    from opus_amd.host import translator as T
+    from oracle.query_oracle import parse_translated_file
+    q = ("SELECT ?type ?prop ?val WHERE { <e> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> ?type . <e> ?prop ?val }")
+    tr = T.translate_query("q", q, lambda u: {"<e>": ["<C>"]}.get(u, []), {"<C>": ["1", "2"]}, {"00001": 5, "00002": 3},
+                           lambda part, uri: ["s_p1_", "o_p9_", "s_http___x_q_"])
+    qm, parts, tp = parse_translated_file(tr)
+    assert tp == 2
+    assert sorted(parts) == ["00002-_3=_http___www_w3_org_1999_02_22_rdf_syntax_ns_type_", "00002-_3=_http___x_q_", "00002-_3=_p1_"]
+    assert qm["X"] == (
+        "SELECT tab0.type AS type,tab1.prop AS prop,tab1.val AS val FROM "
+        "(SELECT o AS type FROM table00002__3_E__http___www_w3_org_1999_02_22_rdf_syntax_ns_type_ WHERE s == '<e>') AS tab0, "
+        "( (SELECT o AS val, '<00002-_3=_p1_>' AS prop FROM table00002__3_E__p1_ WHERE s == '<e>')UNION"
+        "(SELECT o AS val, '<00002-_3=_http___x_q_>' AS prop FROM table00002__3_E__http___x_q_ WHERE s == '<e>') ) AS tab1")
+    with pytest.raises(NotImplementedError):  # without the VP index the reference cannot place the pattern either
+        T.translate_query("q", q, lambda u: ["<C>"], {"<C>": ["1"]}, {"00001": 5})
+
+
+def test_query_shapes_fixture_instantiates():
+    import json
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shape_queries as SQ
+    from opus_amd.workloads import hetero
+    from oracle import dap_oracle
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "query_shapes.json")))
+    assert sum(x["files"] for x in shapes["dbpedia"]) == 112 and sum(x["files"] for x in shapes["swdf/swdf(u)"]) == 279
+    text, _, _ = hetero.generate("swdf", 5000, seed=2)
+    index = SQ.TripleIndex(dap_oracle.parse_instances(text))
+    rng = random.Random(0)
+    done = sum(SQ.instantiate(sh["patterns"], index, rng) is not None for lst in shapes.values() for sh in lst)
+    assert done >= 35
