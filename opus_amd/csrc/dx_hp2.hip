@@ -68,11 +68,9 @@ __device__ __forceinline__ uint64_t hash_key2(int64_t a, int64_t b) { return mix
 
 // Constants -> term ids, on the device, so the host never waits for them. One wave per constant:
 // lane 0 walks the probe chain, then all lanes compare the bytes eight at a time.
-__global__ void __launch_bounds__(64)
-k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask,
-                 const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
-  const int i = blockIdx.x, lane = threadIdx.x;
-  if (i >= ca.n) return;
+__device__ __forceinline__ void resolve_const(const ConstArgs& ca, int i, int lane, uint64_t seed, const DictSlot* __restrict__ ht,
+                                              uint64_t mask, const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
+                                              int64_t* __restrict__ out) {
   if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) { if (lane == 0) out[i] = ca.preset[i]; return; }
   const uint32_t b = ca.off[i], e = ca.off[i + 1], len = e - b;
   const uint64_t h = ca.hash[i];
@@ -95,6 +93,24 @@ k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, u
   }
   same = __all(same);
   if (lane == 0) out[i] = same ? id : -1;
+}
+__global__ void __launch_bounds__(64)
+k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask,
+                 const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, int64_t* __restrict__ out) {
+  if ((int)blockIdx.x < ca.n) resolve_const(ca, blockIdx.x, threadIdx.x, seed, ht, mask, pool, pool_off, out);
+}
+// Everything a statement needs before its first scan, in one launch (a statement is a chain of short kernels,
+// and the gaps between launches cost as much as the kernels): the row counters are zeroed, the hash-join
+// heads of every step are set to "empty", and the first wave of block i resolves constant i.
+__global__ void __launch_bounds__(256)
+k_query_init(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask, const uint8_t* __restrict__ pool,
+             const uint64_t* __restrict__ pool_off, int64_t* __restrict__ consts, unsigned long long* __restrict__ counters, int n_counters,
+             uint32_t* __restrict__ heads, uint64_t n_heads) {
+  if ((int)blockIdx.x < ca.n && threadIdx.x < 64) resolve_const(ca, blockIdx.x, threadIdx.x, seed, ht, mask, pool, pool_off, consts);
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  if (t < (uint64_t)n_counters) counters[t] = 0;
+  uint4* h4 = reinterpret_cast<uint4*>(heads);  // the arena is a multiple of four words
+  for (uint64_t i = t; i < n_heads / 4; i += stride) h4[i] = make_uint4(kNil, kNil, kNil, kNil);
 }
 
 __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, uint32_t i, int64_t v[3]) {
@@ -128,8 +144,11 @@ k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* _
     int64_t v[3];
     c += arm_row(a, consts, i, v) ? 1u : 0u;
   }
-  c = wave_reduce_u32(c);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
+  // one atomic per block: atomics of thousands of waves on one word are carried out one after another
+  __shared__ uint32_t lds[8];
+  uint32_t block_total;
+  (void)block_excl_scan_256<uint32_t>(c, lds, block_total);
+  if (threadIdx.x == 0 && block_total) atomicAdd(total, (unsigned long long)block_total);
 }
 
 // Filtered scan that appends the projected tuple to `out` (first relation of a plan).
@@ -246,9 +265,11 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
       }
     }
   }
-  if (p.count_only) {
-    local = wave_reduce_u64(local);
-    if (lane == 0 && local) atomicAdd(p.out_count, local);
+  if (p.count_only) {  // one atomic per block
+    __shared__ uint64_t lds64[8];
+    uint64_t block_total;
+    (void)block_excl_scan_256<uint64_t>(local, lds64, block_total);
+    if (threadIdx.x == 0 && block_total) atomicAdd(p.out_count, (unsigned long long)block_total);
   }
 }
 
@@ -511,11 +532,12 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       DevBuf<unsigned long long> counters(pool, MAXSTEPS + 2);
       std::vector<std::vector<DevBuf<int64_t>>> step_cols(nsteps);
       std::vector<DevBuf<uint32_t>> tmp32;
-      DX_HIP(hipEventRecord(ev0, s));
-      DX_HIP(hipMemsetAsync(counters.p, 0, sizeof(unsigned long long) * (MAXSTEPS + 2), s));
-      if (ca.n)
-        hipLaunchKernelGGL(k_resolve_consts, dim3(ca.n), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p,
-                           ctx->dict.ht_mask, ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
+      // The steps are laid out first (buffers, capacities, hash-table sizes) and launched afterwards, behind one
+      // kernel that prepares everything they need: see k_query_init.
+      std::vector<std::function<void()>> launches;
+      std::vector<uint64_t> heads_off;   // per join step: offset of its heads in the arena, in words
+      uint64_t heads_words = 0;
+      DevBuf<uint32_t> heads_arena;
       RelDev I{};
       std::vector<int> I_cls;
       std::vector<uint64_t> step_cap(nsteps, 0);
@@ -527,7 +549,12 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
         if (k == 0) {
           if (count_only) {
             for (const auto& a : r.arms)
-              if (a.t->rows) hipLaunchKernelGGL(k_scan_count, dim3(scan_grid(a.t->rows)), dim3(256), 0, s, arm_dev(r, a), consts.p, cnt);
+              if (a.t->rows) {
+                const ArmDev ad = arm_dev(r, a);
+                const uint64_t rows = a.t->rows;
+                const int64_t* cp = consts.p;
+                launches.push_back([=] { hipLaunchKernelGGL(k_scan_count, dim3(scan_grid(rows)), dim3(256), 0, s, ad, cp, cnt); });
+              }
             break;
           }
           const bool alias = r.arms.size() == 1 && r.arms[0].fs < 0 && r.arms[0].fo < 0 && r.arms[0].src[0] != 2 &&
@@ -539,7 +566,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
             const CatalogTable* t = r.arms[0].t;
             for (int c = 0; c < r.ncols; ++c) I.col[c] = const_cast<int64_t*>(r.arms[0].src[c] == 0 ? t->s : t->o);
             I.cap = (uint32_t)t->rows;
-            DX_HIP(hipMemcpyAsync(cnt, &t->rows, 8, hipMemcpyHostToDevice, s));
+            launches.push_back([=] { DX_HIP(hipMemcpyAsync(cnt, &t->rows, 8, hipMemcpyHostToDevice, s)); });
             step_cap[k] = t->rows;
           } else {
             const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : r.rows_upper, 1);
@@ -547,13 +574,20 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
             I.cap = (uint32_t)cap;
             step_cap[k] = cap;
             for (const auto& a : r.arms)
-              if (a.t->rows) hipLaunchKernelGGL(k_scan_emit, dim3(scan_grid(a.t->rows)), dim3(256), 0, s, arm_dev(r, a), consts.p, I, cnt);
+              if (a.t->rows) {
+                const ArmDev ad = arm_dev(r, a);
+                const uint64_t rows = a.t->rows;
+                const int64_t* cp = consts.p;
+                const RelDev Iv = I;
+                launches.push_back([=] { hipLaunchKernelGGL(k_scan_emit, dim3(scan_grid(rows)), dim3(256), 0, s, ad, cp, Iv, cnt); });
+              }
           }
           I_cls.assign(r.cls, r.cls + r.ncols);
           continue;
         }
         // join with the running intermediate
         ProbeArgs pa{};
+        uint64_t my_heads_off = ~0ull;
         pa.consts = consts.p;
         pa.I = I;
         pa.nkey = 0;
@@ -575,16 +609,21 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
         if (pa.nkey > 0) {
           uint32_t hsize = 1024;
           while (hsize < 2ull * I.cap && hsize < (1u << 31)) hsize <<= 1;
-          tmp32.emplace_back(pool, hsize);
-          uint32_t* heads = tmp32.back().p;
+          my_heads_off = heads_words;
+          heads_words += hsize;
           tmp32.emplace_back(pool, std::max<uint32_t>(I.cap, 1));
           uint32_t* next = tmp32.back().p;
-          DX_HIP(hipMemsetAsync(heads, 0xFF, (size_t)hsize * 4, s));
           BuildArgs ba{};
           ba.I = I; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
-          ba.heads = heads; ba.next = next; ba.hmask = hsize - 1;
-          hipLaunchKernelGGL(k_build, dim3(scan_grid(I.cap)), dim3(256), 0, s, ba);
-          pa.heads = heads; pa.next = next; pa.hmask = hsize - 1;
+          ba.heads = nullptr; ba.next = next; ba.hmask = hsize - 1;
+          const uint32_t icap = I.cap;
+          const uint64_t off_words = my_heads_off;
+          DevBuf<uint32_t>* arena = &heads_arena;
+          launches.push_back([=]() mutable {
+            ba.heads = arena->p + off_words;
+            hipLaunchKernelGGL(k_build, dim3(scan_grid(icap)), dim3(256), 0, s, ba);
+          });
+          pa.next = next; pa.hmask = hsize - 1;
         }
         pa.count_only = count_only ? 1 : 0;
         pa.out_count = cnt;
@@ -605,11 +644,27 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
         for (const auto& a : r.arms) {
           if (!a.t->rows) continue;
           pa.arm = arm_dev(r, a);
-          hipLaunchKernelGGL(k_probe, dim3(scan_grid(a.t->rows)), dim3(256), 0, s, pa);
+          const uint64_t rows = a.t->rows;
+          const uint64_t off_words = my_heads_off;
+          DevBuf<uint32_t>* arena = &heads_arena;
+          ProbeArgs pv = pa;
+          launches.push_back([=]() mutable {
+            if (off_words != ~0ull) pv.heads = arena->p + off_words;
+            hipLaunchKernelGGL(k_probe, dim3(scan_grid(rows)), dim3(256), 0, s, pv);
+          });
         }
         I = out;
         for (int c : new_cls) I_cls.push_back(c);
       }
+      heads_arena = DevBuf<uint32_t>(pool, std::max<uint64_t>(heads_words, 4));
+      DX_HIP(hipEventRecord(ev0, s));
+      {
+        const uint64_t fill_blocks = (heads_words / 4 + 255) / 256;
+        const unsigned grid = (unsigned)std::max<uint64_t>(std::max<uint64_t>(ca.n, 1), std::min<uint64_t>(fill_blocks, 2048));
+        hipLaunchKernelGGL(k_query_init, dim3(grid), dim3(256), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
+                           ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters.p, MAXSTEPS + 2, heads_arena.p, heads_words);
+      }
+      for (auto& f : launches) f();
       DX_HIP(hipMemcpyAsync(hb->counters, counters.p, sizeof(unsigned long long) * (MAXSTEPS + 2), hipMemcpyDeviceToHost, s));
       DX_HIP(hipEventRecord(ev1, s));
       DX_HIP(hipStreamSynchronize(s));
