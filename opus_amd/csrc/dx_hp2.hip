@@ -151,30 +151,49 @@ k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* _
   if (threadIdx.x == 0 && block_total) atomicAdd(total, (unsigned long long)block_total);
 }
 
+// Output rows are claimed from one counter. Thousands of waves claiming for themselves are served one after
+// another by the L2, about 8 ns apiece, which for a selective scan or join is most of the kernel: so a block
+// works on a tile of kTileRows rows, counts what it will emit, claims once per tile, then writes.
+// Small tables take one row per thread (every block gets a tile at once), large ones four.
+constexpr uint64_t kSmallTable = 256ull * 2048;
+__device__ __forceinline__ unsigned long long block_claim(uint32_t mine, unsigned long long* counter, uint32_t& before) {
+  __shared__ uint32_t lds[8];
+  __shared__ unsigned long long base_s;
+  uint32_t total;
+  before = block_excl_scan_256<uint32_t>(mine, lds, total);
+  if (threadIdx.x == 0) base_s = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  const unsigned long long base = base_s;
+  __syncthreads();  // base_s is written again in the next tile
+  return base;
+}
+
 // Filtered scan that appends the projected tuple to `out` (first relation of a plan).
+template <int kRowsPerThread>
 __global__ void __launch_bounds__(256)
 k_scan_emit(ArmDev a, const int64_t* __restrict__ consts, RelDev out, unsigned long long* __restrict__ out_count) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t rounds = (a.rows + stride - 1) / stride;
-  for (uint32_t r = 0; r < rounds; ++r) {
-    const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t v[3];
-    const bool hit = i < a.rows && arm_row(a, consts, i, v);
-    const uint64_t b = __ballot(hit);
-    if (!b) continue;
-    unsigned long long base = 0;
-    if (lane == __ffsll((unsigned long long)b) - 1) base = atomicAdd(out_count, (unsigned long long)__popcll(b));
-    base = __shfl(base, __ffsll((unsigned long long)b) - 1, 64);
-    if (hit) {
-      const unsigned long long pos = base + __popcll(b & lt);
-      if (pos < out.cap) {
+  constexpr int kTileRows = 256 * kRowsPerThread;
+  const uint32_t ntiles = (a.rows + kTileRows - 1) / kTileRows;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform
+    int64_t v[kRowsPerThread][3];
+    uint32_t hits = 0, n = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (k < a.nsrc) out.col[k][pos] = v[k];
-      }
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
+      if (i < a.rows && arm_row(a, consts, i, v[j])) { hits |= 1u << j; ++n; }
     }
+    uint32_t before;
+    unsigned long long pos = block_claim(n, out_count, before) + before;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j)
+      if (hits & (1u << j)) {
+        if (pos < out.cap) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k < a.nsrc) out.col[k][pos] = v[j][k];
+        }
+        ++pos;
+      }
   }
 }
 
@@ -213,55 +232,54 @@ struct ProbeArgs {
 };
 
 // Streams one base-table arm and probes the intermediate's hash table. nkey == 0 is the cross product.
+// Per tile: every thread walks the chains of its rows once to count its matches, the block claims its output
+// rows with one atomic, and the chains are walked again to write (they are short, and in cache by then).
+__device__ __forceinline__ bool probe_match(const ProbeArgs& p, uint32_t r, int64_t k0, int64_t k1) {
+  return p.nkey == 0 || (p.I.col[p.key_col[0]][r] == k0 && (p.nkey < 2 || p.I.col[p.key_col[1]][r] == k1));
+}
+template <int kRowsPerThread>
 __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t rounds = (p.arm.rows + stride - 1) / stride;
+  constexpr int kTileRows = 256 * kRowsPerThread;
   const uint32_t nI = rel_rows(p.I);
+  const uint32_t ntiles = (p.arm.rows + kTileRows - 1) / kTileRows;
   unsigned long long local = 0;
-  for (uint32_t rd = 0; rd < rounds; ++rd) {
-    const uint32_t i = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t v[3];
-    const bool hit = i < p.arm.rows && arm_row(p.arm, p.consts, i, v);
-    uint32_t r = kNil;
-    int64_t k0 = 0, k1 = 0;
-    if (hit) {
-      if (p.nkey == 0) {
-        r = nI ? 0u : kNil;
-      } else {
-        k0 = v[p.key_src[0]];
-        if (p.nkey == 2) k1 = v[p.key_src[1]];
-        const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
-        r = p.heads[(uint32_t)h & p.hmask];
-      }
-    }
-    while (__any(r != kNil)) {
-      bool match = false;
-      if (r != kNil) {
-        match = p.nkey == 0 || (p.I.col[p.key_col[0]][r] == k0 && (p.nkey < 2 || p.I.col[p.key_col[1]][r] == k1));
-      }
-      if (p.count_only) {
-        local += match ? 1 : 0;
-      } else {
-        const uint64_t b = __ballot(match);
-        if (b) {
-          const int leader = __ffsll((unsigned long long)b) - 1;
-          unsigned long long base = 0;
-          if (lane == leader) base = atomicAdd(p.out_count, (unsigned long long)__popcll(b));
-          base = __shfl(base, leader, 64);
-          if (match) {
-            const unsigned long long pos = base + __popcll(b & lt);
-            if (pos < p.out.cap) {
-              for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
-              for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = v[p.new_src[c]];
-            }
-          }
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform
+    int64_t v[kRowsPerThread][3];
+    uint32_t head[kRowsPerThread];
+    uint32_t n = 0;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
+      head[j] = kNil;
+      if (i < p.arm.rows && arm_row(p.arm, p.consts, i, v[j])) {
+        if (p.nkey == 0) {
+          head[j] = nI ? 0u : kNil;
+        } else {
+          const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
+          const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
+          head[j] = p.heads[(uint32_t)h & p.hmask];
         }
       }
-      if (r != kNil) {
-        if (p.nkey == 0) r = (r + 1 < nI) ? r + 1 : kNil;
-        else r = p.next[r];
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      if (p.nkey == 0) { n += head[j] != kNil ? nI : 0u; continue; }
+      const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
+      for (uint32_t r = head[j]; r != kNil; r = p.next[r]) n += probe_match(p, r, k0, k1) ? 1u : 0u;
+    }
+    if (p.count_only) { local += n; continue; }
+    uint32_t before;
+    unsigned long long pos = block_claim(n, p.out_count, before) + before;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      const int64_t k0 = p.nkey ? v[j][p.key_src[0]] : 0, k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
+      for (uint32_t r = head[j]; r != kNil; r = p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : p.next[r]) {
+        if (!probe_match(p, r, k0, k1)) continue;
+        if (pos < p.out.cap) {
+          for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
+          for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = v[j][p.new_src[c]];
+        }
+        ++pos;
       }
     }
   }
@@ -482,6 +500,19 @@ unsigned scan_grid(uint64_t rows) {
   if (g < 1) g = 1;
   return (unsigned)(g > 2048 ? 2048 : g);
 }
+unsigned tile_grid(uint64_t rows, int rows_per_thread) {  // kernels that work on tiles of 256 * rows_per_thread rows
+  uint64_t g = (rows + 256 * rows_per_thread - 1) / (256 * rows_per_thread);
+  if (g < 1) g = 1;
+  return (unsigned)(g > 4096 ? 4096 : g);
+}
+void launch_scan_emit(hipStream_t s, uint64_t rows, const ArmDev& a, const int64_t* consts, const RelDev& out, unsigned long long* cnt) {
+  if (rows <= kSmallTable) hipLaunchKernelGGL(k_scan_emit<1>, dim3(tile_grid(rows, 1)), dim3(256), 0, s, a, consts, out, cnt);
+  else hipLaunchKernelGGL(k_scan_emit<4>, dim3(tile_grid(rows, 4)), dim3(256), 0, s, a, consts, out, cnt);
+}
+void launch_probe(hipStream_t s, uint64_t rows, const ProbeArgs& p) {
+  if (rows <= kSmallTable) hipLaunchKernelGGL(k_probe<1>, dim3(tile_grid(rows, 1)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_probe<4>, dim3(tile_grid(rows, 4)), dim3(256), 0, s, p);
+}
 
 }  // namespace
 
@@ -579,7 +610,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
                 const uint64_t rows = a.t->rows;
                 const int64_t* cp = consts.p;
                 const RelDev Iv = I;
-                launches.push_back([=] { hipLaunchKernelGGL(k_scan_emit, dim3(scan_grid(rows)), dim3(256), 0, s, ad, cp, Iv, cnt); });
+                launches.push_back([=] { launch_scan_emit(s, rows, ad, cp, Iv, cnt); });
               }
           }
           I_cls.assign(r.cls, r.cls + r.ncols);
@@ -650,7 +681,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
           ProbeArgs pv = pa;
           launches.push_back([=]() mutable {
             if (off_words != ~0ull) pv.heads = arena->p + off_words;
-            hipLaunchKernelGGL(k_probe, dim3(scan_grid(rows)), dim3(256), 0, s, pv);
+            launch_probe(s, rows, pv);
           });
         }
         I = out;
@@ -894,7 +925,7 @@ dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode) {
     for (int c = 0; c < r.ncols; ++c) { a.own.emplace_back(pool, cap); a.col[c] = a.own.back().p; out.col[c] = a.col[c]; }
     DX_HIP(hipMemsetAsync(counter.p, 0, 8, s));
     for (const auto& arm : r.arms)
-      if (arm.t->rows) hipLaunchKernelGGL(k_scan_emit, dim3(scan_grid(arm.t->rows)), dim3(256), 0, s, arm_dev(r, arm), consts.p, out, counter.p);
+      if (arm.t->rows) launch_scan_emit(s, arm.t->rows, arm_dev(r, arm), consts.p, out, counter.p);
     a.rows = read_counter();
     return a;
   };
@@ -1002,7 +1033,7 @@ dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode) {
         }
         pa.out = od;
         DX_HIP(hipMemsetAsync(counter.p, 0, 8, s));
-        if (A2.rows) hipLaunchKernelGGL(k_probe, dim3(scan_grid(A2.rows)), dim3(256), 0, s, pa);
+        if (A2.rows) launch_probe(s, A2.rows, pa);
         out.rows = read_counter();
         if (count_only || out.rows <= cap) break;
         if (attempt) throw DxError(DX_E_RANGE, "join output did not fit its exact size");
