@@ -333,6 +333,26 @@ __device__ __forceinline__ uint32_t diff_lds_global(const uint32_t* win, uint32_
   return diff;
 }
 
+// len bytes at window offset pa against len bytes at window offset pb, both in LDS (two occurrences of one tile)
+__device__ __forceinline__ uint32_t diff_lds_lds(const uint32_t* win, uint32_t pa, uint32_t pb, uint32_t len) {
+  uint32_t diff = 0;
+  uint32_t ia = pa >> 2, ib = pb >> 2;
+  const uint32_t sa = pa & 3, sb = pb & 3;
+  uint32_t la = win[ia], lb = win[ib];
+  uint32_t j = 0;
+  for (; j + 4 <= len; j += 4) {
+    const uint32_t ha = win[++ia], hb = win[++ib];
+    diff |= __builtin_amdgcn_alignbyte(ha, la, sa) ^ __builtin_amdgcn_alignbyte(hb, lb, sb);
+    la = ha;
+    lb = hb;
+  }
+  if (j < len) {
+    const uint32_t x = __builtin_amdgcn_alignbyte(win[ia + 1], la, sa) ^ __builtin_amdgcn_alignbyte(win[ib + 1], lb, sb);
+    diff |= x & ((1u << (8 * (len - j))) - 1u);
+  }
+  return diff;
+}
+
 // Claims or finds the slot of hash h and lowers its representative to `mine` if that is earlier in the text.
 // Returns the slot; `holder` = a representative that was in the slot before this call took effect (some other
 // occurrence that claims the same string), or kNoHolder for the very first claim. Every occurrence but that
@@ -632,7 +652,11 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
         if (len != (holder[k] & ((1ull << kRepLenBits) - 1))) { differ = true; continue; }
         const uint64_t own = out.rep[k] >> kRepLenBits;
         const uint8_t* hb = text + (holder[k] >> kRepLenBits);
-        if (own >= tile0 && own + len <= tile0 + win_bytes) differ |= diff_lds_global(win, (uint32_t)(own - tile0) + TK_PRE, (uint32_t)len, hb) != 0;
+        const uint64_t hold = holder[k] >> kRepLenBits;
+        const bool own_in = own >= tile0 && own + len <= tile0 + win_bytes;
+        const bool hold_in = hold >= tile0 && hold + len <= tile0 + win_bytes;  // e.g. the wave's first lane with this term
+        if (own_in && hold_in) differ |= diff_lds_lds(win, (uint32_t)(own - tile0) + TK_PRE, (uint32_t)(hold - tile0) + TK_PRE, (uint32_t)len) != 0;
+        else if (own_in) differ |= diff_lds_global(win, (uint32_t)(own - tile0) + TK_PRE, (uint32_t)len, hb) != 0;
         else differ |= diff_global(text + own, hb, len) != 0;  // a record that ran past the staged window
       }
       if (differ) coll[0] = 1;
