@@ -64,10 +64,6 @@ __device__ __forceinline__ uint32_t flags_to_nibble(uint32_t f) {
   const uint32_t y = f >> 7;
   return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
 }
-// Is the byte at offset i (prev = the byte before it) the first byte of a line?
-__device__ __forceinline__ bool line_starts_here(uint8_t prev, uint8_t cur) {
-  return prev == '\n' || (prev == '\r' && cur != '\n');
-}
 
 // One pass over the text, branch-free SWAR on 16 bytes per lane: writes for every 16-byte chunk the
 // 16-bit mask of the bytes that start a record, and per 32 KiB tile the number of records starting in
@@ -516,7 +512,7 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     ++p;
     if (lds_byte(win, p) <= 0x20) {
       while (p < limit && is_jws(lds_byte(win, p))) ++p;
-      odd |= (lds_byte(win, p) <= 0x20) & !is_eol(lds_byte(win, p));  // an empty object is fine
+      odd |= (lds_byte(win, p) <= 0x20) && !is_eol(lds_byte(win, p));  // an empty object is fine
     }
     b[2] = p;
     {  // end of line: first LF / CR at or after the object's first byte, four words per round
@@ -1552,7 +1548,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   uint64_t seed = 0x243F6A8885A308D3ull;
   uint32_t n_terms = 0;
   float ms_tok = 0, ms_clear = 0, ms_first = 0;
-  for (int attempt = 0;; ++attempt) {
+  for (;;) {
     hipEvent_t e0, e1, e2, e3;
     DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2)); DX_HIP(hipEventCreate(&e3));
     // ---- 2./3. tokenise + hash + dictionary slots + byte comparison, in one pass over the text

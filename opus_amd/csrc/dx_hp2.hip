@@ -566,7 +566,6 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
       // The steps are laid out first (buffers, capacities, hash-table sizes) and launched afterwards, behind one
       // kernel that prepares everything they need: see k_query_init.
       std::vector<std::function<void()>> launches;
-      std::vector<uint64_t> heads_off;   // per join step: offset of its heads in the arena, in words
       uint64_t heads_words = 0;
       DevBuf<uint32_t> heads_arena;
       RelDev I{};
