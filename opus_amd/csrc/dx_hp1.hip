@@ -1242,6 +1242,17 @@ __global__ void __launch_bounds__(256) k_node_bit_in(const uint8_t* __restrict__
   if (i < n && in[i]) flags[i] |= kFlagNode;
 }
 
+// src[i] / len[i] = where term ids[i] starts in the pool and how long it is
+__global__ void __launch_bounds__(256)
+k_term_spans(const uint32_t* __restrict__ ids, uint32_t n, const uint64_t* __restrict__ pool_off, uint64_t* __restrict__ src,
+             uint32_t* __restrict__ len) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t b = pool_off[ids[i]];
+  src[i] = b;
+  len[i] = (uint32_t)(pool_off[ids[i] + 1] - b);
+}
+
 int bits_for(uint64_t n) {  // bits needed for values in [0, n)
   int b = 1;
   while ((1ull << b) < n) ++b;
@@ -1894,25 +1905,29 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
 
   // ---- host-side catalogue of tables
   {
-    std::vector<int64_t> ids(ps.pred_terms.begin(), ps.pred_terms.end());
-    std::vector<uint64_t> offs(np + 1);
-    uint64_t total = 0;
     if (np) {
-      std::vector<uint64_t> po(np * 2);
-      for (uint32_t i = 0; i < np; ++i)  // queued copies, one wait
-        DX_HIP(hipMemcpyAsync(&po[2 * i], d.pool_off.p + ids[i], 16, hipMemcpyDeviceToHost, s));
+      // predicate strings: lengths gathered on the device, bytes packed on the device, two copies in all
+      // (a schema with ten thousand predicates would otherwise queue twenty thousand small copies)
+      DevBuf<uint32_t> d_ids(pool, np), d_len(pool, (size_t)np + 1);
+      DevBuf<uint64_t> d_src(pool, np), d_off(pool, (size_t)np + 1), d_tot(pool, 1);
+      const std::vector<uint32_t> ids32(ps.pred_terms.begin(), ps.pred_terms.end());
+      DX_HIP(hipMemcpyAsync(d_ids.p, ids32.data(), (size_t)np * 4, hipMemcpyHostToDevice, s));
+      DX_HIP(hipMemsetAsync(d_len.p + np, 0, 4, s));
+      hipLaunchKernelGGL(k_term_spans, dim3(blocks(np)), dim3(256), 0, s, d_ids.p, np, d.pool_off.p, d_src.p, d_len.p);
+      exclusive_scan_u32_u64(pool, d_len.p, d_off.p, (size_t)np + 1, d_tot.p, s);
+      std::vector<uint64_t> off(np + 1);
+      DX_HIP(hipMemcpyAsync(off.data(), d_off.p, ((size_t)np + 1) * 8, hipMemcpyDeviceToHost, s));
       DX_HIP(hipStreamSynchronize(s));
-      for (uint32_t i = 0; i < np; ++i) ps.pred_strings.emplace_back(po[2 * i + 1] - po[2 * i], '\0');
-      for (uint32_t i = 0; i < np; ++i)
-        if (!ps.pred_strings[i].empty())
-          DX_HIP(hipMemcpyAsync(&ps.pred_strings[i][0], d.pool.p + po[2 * i], ps.pred_strings[i].size(), hipMemcpyDeviceToHost, s));
+      DevBuf<uint8_t> packed(pool, off[np] + 16);
+      hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * np)), dim3(256), 0, s, d.pool.p, d_src.p, d_off.p, (uint64_t)np, packed.p);
+      std::string bytes(off[np], '\0');
+      if (off[np]) DX_HIP(hipMemcpyAsync(&bytes[0], packed.p, off[np], hipMemcpyDeviceToHost, s));
       DX_HIP(hipStreamSynchronize(s));
       for (uint32_t i = 0; i < np; ++i) {
+        ps.pred_strings.emplace_back(bytes.substr(off[i], off[i + 1] - off[i]));
         ps.pred_storage.push_back(uri_to_storage(ps.pred_strings[i]));
-        total += ps.pred_strings[i].size();
       }
     }
-    (void)total; (void)offs;
     for (int q = 0; q < nparts; ++q) {
       uint64_t end = h_part_base[q + 1];
       for (int64_t p = (int64_t)np - 1; p >= 0; --p) {
