@@ -1928,22 +1928,23 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
         ps.pred_storage.push_back(uri_to_storage(ps.pred_strings[i]));
       }
     }
-    for (int q = 0; q < nparts; ++q) {
+    std::vector<uint8_t> pred_in_layout(np);
+    for (uint32_t p = 0; p < np; ++p) pred_in_layout[p] = utf16_units(ps.pred_strings[p]) < 150;  // DAP.scala:434
+    for (int q = 0; q < nparts; ++q) {  // tables in (partition, predicate index) order
+      const size_t first = ps.tables.size();
       uint64_t end = h_part_base[q + 1];
-      for (int64_t p = (int64_t)np - 1; p >= 0; --p) {
+      for (int64_t p = (int64_t)np - 1; p >= 0; --p) {  // a table ends where the next one present begins
         const uint32_t stt = h_tstart[(size_t)q * np + p];
         if (stt == kNil) continue;
         VpTable t;
         t.partition = q; t.pidx = (uint32_t)p; t.pred_term = ps.pred_terms[p];
         t.begin = stt; t.rows = end - stt;
-        t.in_layout = utf16_units(ps.pred_strings[p]) < 150;  // DAP.scala:434
+        t.in_layout = pred_in_layout[p] != 0;
         ps.tables.push_back(t);
         end = stt;
       }
+      std::reverse(ps.tables.begin() + first, ps.tables.end());
     }
-    std::sort(ps.tables.begin(), ps.tables.end(), [](const VpTable& a, const VpTable& b) {
-      return a.partition != b.partition ? a.partition < b.partition : a.pidx < b.pidx;
-    });
     st.n_tables = (uint32_t)ps.tables.size();
   }
   // ---- stage times
