@@ -1260,12 +1260,21 @@ int bits_for(uint64_t n) {  // bits needed for values in [0, n)
 }
 inline unsigned blocks(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per ? (n + per - 1) / per : 1); }
 
+// event i of the context's pool, created on first use (creating and destroying a dozen events per call costs
+// more host time than some of the stages they time)
+hipEvent_t pooled_event(dx_ctx* ctx, size_t i) {
+  while (ctx->part_events.size() <= i) {
+    hipEvent_t e;
+    DX_HIP(hipEventCreate(&e));
+    ctx->part_events.push_back(e);
+  }
+  return ctx->part_events[i];
+}
 struct StageTimer {
-  hipStream_t s;
+  dx_ctx* ctx;
   std::vector<hipEvent_t> ev;
-  explicit StageTimer(hipStream_t st) : s(st) { mark(); }
-  void mark() { hipEvent_t e; DX_HIP(hipEventCreate(&e)); DX_HIP(hipEventRecord(e, s)); ev.push_back(e); }
-  ~StageTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+  explicit StageTimer(dx_ctx* c) : ctx(c) { mark(); }
+  void mark() { hipEvent_t e = pooled_event(ctx, 4 + ev.size()); DX_HIP(hipEventRecord(e, ctx->stream)); ev.push_back(e); }
 };
 
 }  // namespace
@@ -1522,7 +1531,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   ps.n_partitions = nparts;
   dx_part_stats& st = ps.stats;
   st.n_bytes = n_bytes;
-  StageTimer tm(s);
+  StageTimer tm(ctx);
 
   // ---- 1. record starts
   const unsigned ntiles = (unsigned)((n_bytes + LS_TILE - 1) / LS_TILE);
@@ -1560,8 +1569,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   uint32_t n_terms = 0;
   float ms_tok = 0, ms_clear = 0, ms_first = 0;
   for (;;) {
-    hipEvent_t e0, e1, e2, e3;
-    DX_HIP(hipEventCreate(&e0)); DX_HIP(hipEventCreate(&e1)); DX_HIP(hipEventCreate(&e2)); DX_HIP(hipEventCreate(&e3));
+    const hipEvent_t e0 = pooled_event(ctx, 0), e1 = pooled_event(ctx, 1), e2 = pooled_event(ctx, 2), e3 = pooled_event(ctx, 3);
     // ---- 2./3. tokenise + hash + dictionary slots + byte comparison, in one pass over the text
     DX_HIP(hipEventRecord(e0, s));
     hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
@@ -1582,7 +1590,6 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipMemcpyAsync(&n_terms, d_total.p, 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
     DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_first, e2, e3));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
                                         " (empty line, fewer than three fields, or a term of 16 MiB or more)");
