@@ -116,6 +116,30 @@ int dx_vp_index_fetch(dx_ctx* ctx, int partition, int64_t* uri, int32_t* role, i
 int dx_instance_graph_sizes(dx_ctx* ctx, int64_t* n_vertices, int64_t* n_edges);
 int dx_instance_graph_fetch(dx_ctx* ctx, int64_t* vertex_terms, int64_t* edge_src, int64_t* edge_dst, int64_t* edge_pred);
 
+/* Instance-scale inputs of the schema clustering, computed from the state dx_partition* left on the GPU
+ * (replaces Preprocessor.computeCC :230-264, computeSchemaNodeFreq :312-326 and computeSchemaNodeCount
+ * :328-339, called from DAP.main through Preprocessor.computeMeasures, DAP.scala:82). Type lists keep
+ * their multiplicity, as the reference's Seq[String] does: a type triple stated twice counts twice.
+ *   dx_measures_compute   runs the kernels; n_classes = classes that type a subject, n_cc = (subType, pred,
+ *                         objType) groups; device_ms = GPU time of the call.
+ *   dx_measures_classes   per class (ascending term id): the class, its schema_node_freq.txt value (occurrences
+ *                         in the type lists of distinct typed endpoints of edges; 0 = no line in the file) and its
+ *                         schema_node_count.txt value (occurrences over all edges with a typed endpoint).
+ *   dx_measures_cc        per group, ordered by (subType, pred, objType) in class / predicate order: rows and
+ *                         distinct object instances (the two numbers of a schema_cc line).
+ *   dx_measures_write     <base><dataset>_data/schema_cc/part-00000 (+ _SUCCESS) with the text lines
+ *                         "((subType,pred,objType),rows,dist)" that Loader.loadCC parses (Loader.scala:318-322),
+ *                         <local_dir><dataset>_local/schema_node_freq.txt and schema_node_count.txt
+ *                         ("class\tvalue", descending value; Constatnts.scala:13,34,40). */
+typedef struct dx_measure_sizes {
+  uint64_t n_classes, n_cc, n_type_entries, n_cc_rows;
+  double device_ms;
+} dx_measure_sizes;
+int dx_measures_compute(dx_ctx* ctx, dx_measure_sizes* out);
+int dx_measures_classes(dx_ctx* ctx, int64_t* class_term, int64_t* node_freq, int64_t* node_count);
+int dx_measures_cc(dx_ctx* ctx, int64_t* sub_type, int64_t* pred, int64_t* obj_type, int64_t* rows, int64_t* dist);
+int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
+
 /* Writes <base><dataset>_data/... and <dataset>_local/... as the reference lays them out
  * (Constatnts.scala:9-40), with int64 column files beside the directory names the Scala tools expect. */
 int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);

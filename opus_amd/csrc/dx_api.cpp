@@ -427,6 +427,95 @@ int dx_instance_graph_fetch(dx_ctx* ctx, int64_t* vertex_terms, int64_t* edge_sr
   });
 }
 
+// ---- instance-scale measures (Preprocessor.scala:230-264, 312-339) -----------------------------------------
+int dx_measures_compute(dx_ctx* ctx, dx_measure_sizes* out) {
+  return guard(ctx, [&] { run_measures(ctx, out); });
+}
+
+int dx_measures_classes(dx_ctx* ctx, int64_t* class_term, int64_t* node_freq, int64_t* node_count) {
+  return guard(ctx, [&] {
+    const MeasureState& ms = ctx->measures;
+    if (!ms.valid) throw DxError(DX_E_INVAL, "dx_measures_compute has not run");
+    const size_t n = ms.class_term.size() * 8;
+    if (n) {
+      memcpy(class_term, ms.class_term.data(), n);
+      memcpy(node_freq, ms.node_freq.data(), n);
+      memcpy(node_count, ms.node_count.data(), n);
+    }
+  });
+}
+
+int dx_measures_cc(dx_ctx* ctx, int64_t* sub_type, int64_t* pred, int64_t* obj_type, int64_t* rows, int64_t* dist) {
+  return guard(ctx, [&] {
+    const MeasureState& ms = ctx->measures;
+    if (!ms.valid) throw DxError(DX_E_INVAL, "dx_measures_compute has not run");
+    const size_t n = ms.cc_rows.size() * 8;
+    if (n) {
+      memcpy(sub_type, ms.cc_sub.data(), n);
+      memcpy(pred, ms.cc_pred.data(), n);
+      memcpy(obj_type, ms.cc_obj.data(), n);
+      memcpy(rows, ms.cc_rows.data(), n);
+      memcpy(dist, ms.cc_dist.data(), n);
+    }
+  });
+}
+
+static std::vector<std::string> decode_terms(dx_ctx* ctx, const std::vector<int64_t>& ids) {
+  std::vector<std::string> out(ids.size());
+  if (ids.empty()) return out;
+  uint64_t total = 0;
+  int rc = dx_terms_bytes(ctx, ids.data(), ids.size(), &total);
+  if (rc) throw DxError(rc, ctx->err);
+  std::string bytes(total, '\0');
+  std::vector<uint64_t> off(ids.size() + 1);
+  rc = dx_terms_decode(ctx, ids.data(), ids.size(), total ? &bytes[0] : nullptr, total, off.data());
+  if (rc) throw DxError(rc, ctx->err);
+  for (size_t i = 0; i < ids.size(); ++i) out[i] = bytes.substr(off[i], off[i + 1] - off[i]);
+  return out;
+}
+
+int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
+  return guard(ctx, [&] {
+    const MeasureState& ms = ctx->measures;
+    if (!ms.valid || !dataset) throw DxError(DX_E_INVAL, "dx_measures_compute has not run / null dataset");
+    const std::string B = norm_base(base), D = dataset;
+    std::string L = local_dir ? local_dir : "";
+    if (!L.empty() && L.back() != '/') L += '/';
+    const std::vector<std::string> cls = decode_terms(ctx, ms.class_term);
+    std::map<int64_t, const std::string*> by_term;
+    for (size_t i = 0; i < cls.size(); ++i) by_term[ms.class_term[i]] = &cls[i];
+    // schema_cc: what RDD[((String, String, String), Long, Long)].saveAsTextFile writes (Preprocessor.scala:261-262)
+    const std::string cc = B + D + "_data/schema_cc";
+    struct stat stt;
+    if (stat(cc.c_str(), &stt) == 0)  // Preprocessor.scala:37: skipped when it exists; saveAsTextFile itself refuses to overwrite
+      throw DxError(DX_E_INVAL, cc + " already exists (the reference skips the computation in that case; remove it to rewrite)");
+    mkdirs(cc);
+    {
+      const std::vector<std::string> preds = decode_terms(ctx, ms.cc_pred);
+      std::ofstream f(cc + "/part-00000", std::ios::binary);
+      for (size_t g = 0; g < ms.cc_rows.size(); ++g)
+        f << "((" << *by_term[ms.cc_sub[g]] << "," << preds[g] << "," << *by_term[ms.cc_obj[g]] << ")," << ms.cc_rows[g] << "," << ms.cc_dist[g]
+          << ")\n";
+      if (!f) throw DxError(DX_E_IO, "writing " + cc + " failed");
+    }
+    touch(cc + "/_SUCCESS");
+    // schema_node_freq.txt / schema_node_count.txt: "class\tvalue", descending value (Preprocessor.scala:321-325, 334-338);
+    // equal values are ordered by class term id here (the reference leaves them in no particular order)
+    mkdirs(L + D + "_local");
+    auto write_sorted = [&](const std::string& path, const std::vector<int64_t>& v) {
+      std::vector<size_t> idx;
+      for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] > 0) idx.push_back(i);  // a class that never reaches the reduceByKey has no line
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return v[a] > v[b]; });
+      std::ofstream f(path, std::ios::binary);
+      for (size_t i : idx) f << cls[i] << "\t" << v[i] << "\n";
+      if (!f) throw DxError(DX_E_IO, "writing " + path + " failed");
+    };
+    write_sorted(L + D + "_local/schema_node_freq.txt", ms.node_freq);
+    write_sorted(L + D + "_local/schema_node_count.txt", ms.node_count);
+  });
+}
+
 // ---- on-disk layout -----------------------------------------------------------------------------------
 int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
   return guard(ctx, [&] {

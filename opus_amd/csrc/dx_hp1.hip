@@ -1526,6 +1526,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   ctx->catalog.clear();
   ctx->table_stats.clear();
   ctx->part = PartitionState();
+  ctx->measures = MeasureState();
   ctx->dict = Dictionary();
   PartitionState& ps = ctx->part;
   ps.n_partitions = nparts;

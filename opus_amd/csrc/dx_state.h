@@ -69,6 +69,15 @@ struct PartitionState {
   DevBuf<uint8_t> term_flags;         // per term: bit0 = literal (starts with '"'), bit1 = vertex, bit2 = has edge
 };
 
+// Instance-scale measures (schema_cc, schema_node_freq, schema_node_count) of the last partition run, on the host:
+// they are schema-sized.
+struct MeasureState {
+  bool valid = false;
+  std::vector<int64_t> class_term, node_freq, node_count;           // per class, ascending term id
+  std::vector<int64_t> cc_sub, cc_pred, cc_obj, cc_rows, cc_dist;   // per (subType, pred, objType) group
+  uint64_t n_type_entries = 0, n_cc_rows = 0;
+};
+
 struct CatalogTable {
   std::string key;      // "00001-_3=<pred>"
   std::string view;     // "table00001__3_E_<pred>"
@@ -97,6 +106,7 @@ struct dx_ctx {
   dx::DevPool pool;
   dx::Dictionary dict;
   dx::PartitionState part;
+  dx::MeasureState measures;
   std::map<std::string, dx::CatalogTable> catalog;   // by view name
   std::map<std::string, std::pair<uint64_t, uint64_t>> table_stats;  // by table key: distinct s, distinct o
   // dataset opened from disk
@@ -129,6 +139,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const s
 void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids_host);
 void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
 void table_statistics(dx_ctx* ctx, CatalogTable& t);  // distinct subjects / objects
+// dx_measures.hip
+void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
 dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode);

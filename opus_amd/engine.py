@@ -32,6 +32,7 @@ EXPORTS = [
     "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
+    "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write",
 ]
 
 
@@ -53,6 +54,11 @@ class PartStats(ctypes.Structure):
         d["ms_stage"] = {lib.dx_part_stage_name(i).decode(): self.ms_stage[i] for i in range(12)
                          if lib.dx_part_stage_name(i)}
         return d
+
+
+class MeasureSizes(ctypes.Structure):
+    _fields_ = [("n_classes", c_uint64), ("n_cc", c_uint64), ("n_type_entries", c_uint64), ("n_cc_rows", c_uint64),
+                ("device_ms", c_double)]
 
 
 class TableInfo(ctypes.Structure):
@@ -98,6 +104,10 @@ def load_library():
         "dx_vp_index_fetch": (c_int, [c_void_p, c_int, i64p, i32p, i64p]),
         "dx_instance_graph_sizes": (c_int, [c_void_p, i64p, i64p]),
         "dx_instance_graph_fetch": (c_int, [c_void_p, i64p, i64p, i64p, i64p]),
+        "dx_measures_compute": (c_int, [c_void_p, ctypes.POINTER(MeasureSizes)]),
+        "dx_measures_classes": (c_int, [c_void_p, i64p, i64p, i64p]),
+        "dx_measures_cc": (c_int, [c_void_p, i64p, i64p, i64p, i64p, i64p]),
+        "dx_measures_write": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
         "dx_part_write_layout": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
         "dx_open_dataset": (c_int, [c_void_p, c_char_p, c_char_p, c_int]),
         "dx_load_table": (c_int, [c_void_p, c_char_p, u64p]),
@@ -306,6 +316,22 @@ class Engine:
         v, es, ed, ep = _i64(nv.value), _i64(ne.value), _i64(ne.value), _i64(ne.value)
         self._check(self.lib.dx_instance_graph_fetch(self.ctx, _p(v), _p(es), _p(ed), _p(ep)))
         return v, es, ed, ep
+
+    def measures(self):
+        """Instance-scale inputs of the schema clustering (Preprocessor.scala:230-264, 312-339) from the last
+        partition run: (sizes, classes, cc) with classes = (class term, node freq, node count) arrays and
+        cc = (subType, pred, objType, rows, distinct object instances) arrays, all as term ids."""
+        sz = MeasureSizes()
+        self._check(self.lib.dx_measures_compute(self.ctx, byref(sz)))
+        c, f, k = _i64(sz.n_classes), _i64(sz.n_classes), _i64(sz.n_classes)
+        self._check(self.lib.dx_measures_classes(self.ctx, _p(c), _p(f), _p(k)))
+        cc = tuple(_i64(sz.n_cc) for _ in range(5))
+        self._check(self.lib.dx_measures_cc(self.ctx, *[_p(a) for a in cc]))
+        sizes = {k_: getattr(sz, k_) for k_, _ in MeasureSizes._fields_}
+        return sizes, (c, f, k), cc
+
+    def write_measures(self, base: str, dataset: str, local_dir: str = ""):
+        self._check(self.lib.dx_measures_write(self.ctx, base.encode(), dataset.encode(), local_dir.encode()))
 
     def write_layout(self, base: str, dataset: str, local_dir: str = ""):
         self._check(self.lib.dx_part_write_layout(self.ctx, base.encode(), dataset.encode(), local_dir.encode()))

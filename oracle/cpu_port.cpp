@@ -46,6 +46,9 @@ struct Result {
   uint64_t n_triples = 0, n_vertices = 0, n_edges = 0, n_node_index = 0, n_tables = 0;
   std::vector<uint64_t> part_rows;
   std::vector<uint64_t> part_digest;  // order-independent digest of the partition's (s, o, p) strings
+  // instance-scale measures, strings as their FNV-1a hashes: (class, node freq, node count) and
+  // (subType, pred, objType, rows, distinct object instances)
+  std::vector<uint64_t> classes, cc;
   int error = 0;
 };
 
@@ -56,7 +59,8 @@ uint64_t fnv(sv s) {
 }
 uint64_t mix(uint64_t h) { h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; return h ^ (h >> 33); }
 
-Result* run(const char* text, uint64_t n, const char* class_index, int nparts) {
+Result* run(const char* text, uint64_t n, const char* class_index, int nparts, double* seconds) {
+  const auto t0 = std::chrono::steady_clock::now();
   auto* res = new Result();
   res->part_rows.assign(nparts, 0);
   res->part_digest.assign(nparts, 0);
@@ -182,18 +186,71 @@ Result* run(const char* text, uint64_t n, const char* class_index, int nparts) {
   std::sort(node.begin(), node.end());
   node.erase(std::unique(node.begin(), node.end()), node.end());
   res->n_node_index = node.size();
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  // ---- instance-scale measures, outside the timed part (Preprocessor.scala:230-264, 312-339)
+  {
+    std::map<uint32_t, std::pair<uint64_t, uint64_t>> per_class;  // class -> (freq, count)
+    std::vector<uint8_t> endpoint(strs.size(), 0);
+    using CcRow = std::tuple<uint32_t, uint32_t, uint32_t, uint32_t>;  // subType, pred, objType, inst2
+    std::vector<CcRow> cc_rows;
+    for (const auto& e : edges) {
+      const V &src = attr[e.s], &dst = attr[e.o];
+      if (src.types.empty() && dst.types.empty()) continue;
+      for (uint32_t c : src.types) ++per_class[c].second;                                 // :329-333
+      for (uint32_t c : dst.types) ++per_class[c].second;
+      if (!src.types.empty()) endpoint[e.s] = 1;                                           // :313-317
+      if (!dst.types.empty()) endpoint[e.o] = 1;
+      for (uint32_t st : src.types)                                                        // :232-241, 356-366
+        for (uint32_t ot : dst.types)
+          if (!strs[st].empty() && !strs[e.p].empty() && !strs[ot].empty()) cc_rows.emplace_back(st, e.p, ot, e.o);
+    }
+    for (size_t v = 0; v < strs.size(); ++v)
+      if (endpoint[v])
+        for (uint32_t c : attr[v].types) ++per_class[c].first;                            // :318-320
+    for (auto& kv : per_class) {
+      res->classes.push_back(fnv(strs[kv.first]));
+      res->classes.push_back(kv.second.first);
+      res->classes.push_back(kv.second.second);
+    }
+    std::sort(cc_rows.begin(), cc_rows.end());
+    for (size_t i = 0; i < cc_rows.size();) {
+      size_t j = i;
+      uint64_t rows_n = 0, dist = 0;
+      while (j < cc_rows.size() && std::get<0>(cc_rows[j]) == std::get<0>(cc_rows[i]) && std::get<1>(cc_rows[j]) == std::get<1>(cc_rows[i]) &&
+             std::get<2>(cc_rows[j]) == std::get<2>(cc_rows[i])) {
+        ++rows_n;
+        if (j == i || std::get<3>(cc_rows[j]) != std::get<3>(cc_rows[j - 1])) ++dist;     // :246-251
+        ++j;
+      }
+      res->cc.push_back(fnv(strs[std::get<0>(cc_rows[i])]));
+      res->cc.push_back(fnv(strs[std::get<1>(cc_rows[i])]));
+      res->cc.push_back(fnv(strs[std::get<2>(cc_rows[i])]));
+      res->cc.push_back(rows_n);
+      res->cc.push_back(dist);
+      i = j;
+    }
+  }
   return res;
 }
 
 }  // namespace
 
 extern "C" {
-// Runs the restatement; *seconds receives the wall time of the run itself.
+// Runs the restatement; *seconds receives the wall time of the partitioning itself (the measures are computed after it).
 void* cpu_port_run(const char* text, uint64_t n, const char* class_index_text, int nparts, double* seconds) {
-  const auto t0 = std::chrono::steady_clock::now();
-  Result* r = run(text, n, class_index_text, nparts);
-  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  return r;
+  return run(text, n, class_index_text, nparts, seconds);
+}
+// Instance-scale measures of the run: sizes = [classes, cc groups]; classes = 3 words each (FNV-1a of the class, node
+// freq, node count), cc = 5 words each (FNV-1a of subType, pred, objType; rows; distinct object instances).
+void cpu_port_measure_sizes(void* h, uint64_t* sizes) {
+  const Result* r = (const Result*)h;
+  sizes[0] = r->classes.size() / 3;
+  sizes[1] = r->cc.size() / 5;
+}
+void cpu_port_measures(void* h, uint64_t* classes, uint64_t* cc) {
+  const Result* r = (const Result*)h;
+  if (!r->classes.empty()) memcpy(classes, r->classes.data(), r->classes.size() * 8);
+  if (!r->cc.empty()) memcpy(cc, r->cc.data(), r->cc.size() * 8);
 }
 // out: [error, n_triples, n_vertices, n_edges, n_node_index, n_tables, rows[nparts], digest[nparts]]
 void cpu_port_stats(void* h, uint64_t* out) {

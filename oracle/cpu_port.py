@@ -16,6 +16,8 @@ def _lib():
         lib.cpu_port_run.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.cpu_port_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.cpu_port_free.argtypes = [ctypes.c_void_p]
+        lib.cpu_port_measure_sizes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.cpu_port_measures.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.cpu_port_rows_digest.restype = ctypes.c_uint64
         lib.cpu_port_rows_digest.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_uint64]
@@ -53,13 +55,28 @@ def run(text_u8: np.ndarray, class_index_text: str, n_partitions: int) -> dict:
     h = _lib().cpu_port_run(text_u8.ctypes.data, text_u8.size, class_index_text.encode(), n_partitions, ctypes.byref(secs))
     out = np.zeros(6 + 2 * n_partitions, dtype=np.uint64)
     _lib().cpu_port_stats(h, out.ctypes.data)
+    sizes = np.zeros(2, dtype=np.uint64)
+    _lib().cpu_port_measure_sizes(h, sizes.ctypes.data)
+    cls, cc = np.zeros((int(sizes[0]), 3), dtype=np.uint64), np.zeros((int(sizes[1]), 5), dtype=np.uint64)
+    _lib().cpu_port_measures(h, cls.ctypes.data, cc.ctypes.data)
     _lib().cpu_port_free(h)
     if out[0]:
         raise ValueError("malformed N-Triples input")
-    return {"seconds": secs.value, "n_triples": int(out[1]), "n_vertices": int(out[2]), "n_edges": int(out[3]),
+    return {"measures": measures_by_hash(cls, cc), "seconds": secs.value, "n_triples": int(out[1]), "n_vertices": int(out[2]), "n_edges": int(out[3]),
             "n_node_index": int(out[4]), "n_tables": int(out[5]),
             "part_rows": [int(x) for x in out[6:6 + n_partitions]],
             "part_digest": [int(x) for x in out[6 + n_partitions:6 + 2 * n_partitions]]}
+
+
+def measures_by_hash(cls, cc):
+    """{"classes": {hash(class): (node freq, node count)}, "cc": {(hash(subType), hash(pred), hash(objType)): (rows, dist)}}"""
+    return {"classes": {int(r[0]): (int(r[1]), int(r[2])) for r in cls},
+            "cc": {(int(r[0]), int(r[1]), int(r[2])): (int(r[3]), int(r[4])) for r in cc}}
+
+
+def term_hash(b: bytes) -> int:
+    """FNV-1a of a term's bytes: the key of measures_by_hash."""
+    return _fnv(b)
 
 
 def rows_digest(pool: np.ndarray, offs: np.ndarray, s: np.ndarray, o: np.ndarray, p: np.ndarray) -> int:

@@ -261,6 +261,58 @@ def compute_partition_statistics(parts, vp):
     return dict(stat)
 
 
+def compute_cc(vertices, edges):
+    """Preprocessor.computeCC (Preprocessor.scala:230-264; combineTripleTypes :356-366).
+
+    For every instance edge whose endpoints both carry types, one row per (subject type, object type)
+    pair -- the type lists keep duplicates, so a type triple stated twice counts twice -- grouped by
+    (subType, pred, objType). Returns {(subType, pred, objType): (rows, distinct object instances)};
+    the reference saves these as "((subType,pred,objType),rows,dist)" text lines in no particular order."""
+    vattr = {vid: (uri, types, labels) for (vid, uri, types, labels) in vertices}
+    rows = defaultdict(int)
+    inst2 = defaultdict(set)
+    for (s, d, p) in edges:
+        src, dst = vattr[s], vattr[d]
+        if not (src[1] and dst[1]):
+            continue
+        for st in src[1]:
+            for ot in dst[1]:
+                if st and p and ot:  # :241
+                    rows[(st, p, ot)] += 1
+                    inst2[(st, p, ot)].add(dst[0])
+    return {k: (rows[k], len(inst2[k])) for k in rows}
+
+
+def compute_schema_node_freq(vertices, edges):
+    """Preprocessor.computeSchemaNodeFreq (Preprocessor.scala:312-326): over the distinct typed endpoints
+    of edges, the number of times each class occurs in their type lists. {class: freq}; the reference
+    writes "class\tfreq" lines by descending freq (ties in no particular order)."""
+    vattr = {vid: (uri, types, labels) for (vid, uri, types, labels) in vertices}
+    nodes = set()
+    for (s, d, p) in edges:
+        if vattr[s][1] or vattr[d][1]:
+            for v in (s, d):
+                if vattr[v][1]:
+                    nodes.add(v)  # .distinct on (uri, types, labels): one per vertex
+    freq = defaultdict(int)
+    for v in nodes:
+        for c in vattr[v][1]:
+            freq[c] += 1
+    return dict(freq)
+
+
+def compute_schema_node_count(vertices, edges):
+    """Preprocessor.computeSchemaNodeCount (Preprocessor.scala:328-339): every edge with a typed endpoint
+    counts once for each entry of its endpoints' type lists. {class: count}."""
+    vattr = {vid: (uri, types, labels) for (vid, uri, types, labels) in vertices}
+    count = defaultdict(int)
+    for (s, d, p) in edges:
+        if vattr[s][1] or vattr[d][1]:
+            for c in list(vattr[s][1]) + list(vattr[d][1]):
+                count[c] += 1
+    return dict(count)
+
+
 def run_dap(text: str, class_index_text: str, n_partitions: int):
     """The whole post-DAP stage on in-memory inputs; returns a dict of artefacts."""
     triples = parse_instances(text)
@@ -279,4 +331,7 @@ def run_dap(text: str, class_index_text: str, n_partitions: int):
         "vp": vp,
         "vp_index": vp_index,
         "partition_stat": compute_partition_statistics(parts, vp),
+        "schema_cc": compute_cc(vertices, edges),
+        "schema_node_freq": compute_schema_node_freq(vertices, edges),
+        "schema_node_count": compute_schema_node_count(vertices, edges),
     }

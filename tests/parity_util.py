@@ -6,7 +6,17 @@ import numpy as np
 from oracle import dap_oracle
 
 
-def engine_artifacts(e):
+def engine_measures(e, strs):
+    """schema_cc / schema_node_freq / schema_node_count as the oracle's string-keyed dicts."""
+    _, (c, f, k), (a, p, b, rows, dist) = e.measures()
+    freq = {strs[ci]: int(v) for ci, v in zip(c.tolist(), f.tolist()) if v}
+    count = {strs[ci]: int(v) for ci, v in zip(c.tolist(), k.tolist()) if v}
+    cc = {(strs[x], strs[y], strs[z]): (int(r), int(d)) for x, y, z, r, d in zip(a.tolist(), p.tolist(), b.tolist(), rows.tolist(), dist.tolist())}
+    assert len(cc) == len(a), "a (subType, pred, objType) group is reported twice"
+    return {"schema_cc": cc, "schema_node_freq": freq, "schema_node_count": count}
+
+
+def engine_artifacts(e, measures=True):
     strs = e.decode(np.arange(e.term_count(), dtype=np.int64))
     S = lambda a: [strs[i] for i in a]  # noqa: E731
     n = e.partition_count()
@@ -39,7 +49,8 @@ def engine_artifacts(e):
     stat = defaultdict(int)
     for (name, _), rows in vp.items():
         stat[name] += len(rows)
-    return {"strs": strs, "parts": parts, "statistics": statistics, "vp": dict(vp), "node_index": node_index,
+    extra = engine_measures(e, strs) if measures else {}
+    return {**extra, "strs": strs, "parts": parts, "statistics": statistics, "vp": dict(vp), "node_index": node_index,
             "vp_index": vp_index, "vertices": S(v), "edges": set(zip(es.tolist(), ed.tolist(), S(ep))),
             "partition_stat": dict(stat)}
 
@@ -60,3 +71,6 @@ def assert_same_as_oracle(got, ref):
         assert sorted(got["vp"][k]) == sorted(ref["vp"][k]), "VP table %s differs" % (k,)
     assert got["vp_index"] == ref["vp_index"], "VP index differs"
     assert got["partition_stat"] == ref["partition_stat"]
+    for k in ("schema_cc", "schema_node_freq", "schema_node_count"):
+        if k in got and k in ref:
+            assert got[k] == ref[k], "%s differs" % k

@@ -42,7 +42,7 @@ def main(out_path):
     e = Engine(0)
     e.set_comm(comm)
     st = e.partition_text(mine, ci, n_parts)
-    art = engine_artifacts(e)
+    art = engine_artifacts(e, measures=False)
     share = {"rank": rank, "n_terms": int(st.n_terms), "n_unique": int(st.n_unique), "n_edges": int(st.n_edges),
              "n_vertices": int(st.n_vertices), "n_triples_in": int(st.n_triples),
              "parts": [sorted(p) for p in art["parts"]], "node_index": sorted(art["node_index"]),

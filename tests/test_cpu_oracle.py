@@ -189,3 +189,33 @@ def test_query_shapes_fixture_instantiates():
     rng = random.Random(0)
     done = sum(SQ.instantiate(sh["patterns"], index, rng) is not None for lst in shapes.values() for sh in lst)
     assert done >= 35
+
+
+def test_instance_measures_hand_example():
+    """computeCC / computeSchemaNodeFreq / computeSchemaNodeCount on a case worked out by hand from
+    Preprocessor.scala:230-264, 312-339: a is typed [A, A, B] (one type stated twice), b is typed [B], c is
+    untyped; the distinct edges are (a,p,b), (a,p,c), (c,q,b)."""
+    from oracle import dap_oracle as D
+    T = D.RDF_TYPE
+    text = ("<a> %s <A> .\n<a> %s <A> .\n<a> %s <B> .\n<b> %s <B> .\n" % (T, T, T, T) +
+            "<a> <p> <b> .\n<a> <p> <c> .\n<c> <q> <b> .\n<a> <p> <b> .\n")
+    vertices, edges = D.create_instance_graph(D.parse_instances(text))
+    assert D.compute_schema_node_count(vertices, edges) == {"<A>": 4, "<B>": 4}
+    assert D.compute_schema_node_freq(vertices, edges) == {"<A>": 2, "<B>": 2}
+    assert D.compute_cc(vertices, edges) == {("<A>", "<p>", "<B>"): (2, 1), ("<B>", "<p>", "<B>"): (1, 1)}
+
+
+def test_instance_measures_cpp_restatement_agrees_with_python():
+    """The two CPU restatements of computeCC / computeSchemaNodeFreq / computeSchemaNodeCount agree on a
+    multi-typed, many-class input (strings compared through their FNV-1a hashes)."""
+    import numpy as np
+    from opus_amd.workloads import hetero
+    from oracle import cpu_port, dap_oracle as D
+    text, ci, k = hetero.generate("swdf", 6000, seed=3)
+    ref = D.run_dap(text, ci, k)
+    got = cpu_port.run(np.frombuffer(text.encode(), dtype=np.uint8), ci, k)["measures"]
+    H = lambda s: cpu_port.term_hash(s.encode())  # noqa: E731
+    classes = {H(c): (ref["schema_node_freq"].get(c, 0), ref["schema_node_count"].get(c, 0))
+               for c in set(ref["schema_node_count"]) | set(ref["schema_node_freq"])}
+    assert classes == got["classes"] and len(classes) > 10
+    assert {(H(a), H(b), H(c)): v for (a, b, c), v in ref["schema_cc"].items()} == got["cc"]

@@ -81,6 +81,12 @@ EDGE_CASES = {
     # three new terms per record: more terms than the dictionary table's first size has slots, so it regrows
     "all_terms_distinct": ("".join("<s%d> <p%d> <o%d> .\n" % (i, i, i) for i in range(3000)) +
                            "<s1> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n", "<A>\t0,1\n", 2),
+    # type lists keep duplicates (a type stated twice counts twice in the measures); classes named "" are dropped from schema_cc
+    "repeated_types_and_empty_class": (
+        "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n"
+        "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n"
+        "<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> \n<a> <p> <b> .\n<a> <p> <c> .\n<c> <q> <b> .\n<a> <p> <b> .\n<b> <q> <b> .\n",
+        "<A>\t0\n<B>\t1\n", 2),
     "empty_input": ("", "<A>\t0\n", 2),
     "only_comments": ("# nothing\n# here\n", "<A>\t0\n", 2),
 }
@@ -161,3 +167,28 @@ def test_true_hash_collision_is_detected_and_resolved(engine):
     st, got, ref = _run(engine, text, "<A>\t0\n<B>\t1\n", 2)
     assert st.hash_retries >= 1
     assert s1 in got["strs"] and s2 in got["strs"]
+
+
+def test_measure_files(engine, tmp_path):
+    """schema_cc / schema_node_freq.txt / schema_node_count.txt as Loader.loadCC, loadSchemaNodeFreq and
+    loadSchemaNodeCount read them (Loader.scala:318-322, 348-365)."""
+    from opus_amd.engine import DxError
+    from oracle import dap_oracle
+    text, ci, n = EDGE_CASES["repeated_types_and_empty_class"]
+    engine.partition_text(text.encode(), ci, n)
+    sizes, _, _ = engine.measures()
+    ref = dap_oracle.run_dap(text, ci, n)
+    assert sizes["n_cc"] == len(ref["schema_cc"])
+    engine.write_measures(str(tmp_path), "ds", str(tmp_path))
+    cc = {}
+    for line in open(tmp_path / "ds_data" / "schema_cc" / "part-00000"):
+        x = line.rstrip("\n").split(",")  # loadCC: split(","), drop(2) / dropRight(1) around the brackets
+        cc[(x[0][2:], x[1], x[2][:-1])] = (int(x[3]), int(x[4][:-1]))
+    assert cc == ref["schema_cc"]
+    assert os.path.exists(tmp_path / "ds_data" / "schema_cc" / "_SUCCESS")
+    for name, key in (("schema_node_freq.txt", "schema_node_freq"), ("schema_node_count.txt", "schema_node_count")):
+        rows = [ln.rstrip("\n").split("\t") for ln in open(tmp_path / "ds_local" / name)]
+        assert {r[0]: int(r[1]) for r in rows} == ref[key]
+        assert [int(r[1]) for r in rows] == sorted((int(r[1]) for r in rows), reverse=True)
+    with pytest.raises(DxError):  # like saveAsTextFile, never over an existing directory
+        engine.write_measures(str(tmp_path), "ds", str(tmp_path))

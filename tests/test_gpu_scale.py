@@ -39,6 +39,14 @@ def _check_against_cpu_port(e, arr, ci, n, st):
     rows, dig = _digests(e)
     assert rows == ref["part_rows"]
     assert dig == ref["part_digest"]
+    # instance-scale measures: schema-sized, compared value by value (strings through their FNV-1a hashes)
+    _, (c, f, k), (a, p, b, nrows, dist) = e.measures()
+    ids = sorted(set(c.tolist()) | set(a.tolist()) | set(p.tolist()) | set(b.tolist()))
+    h = {i: cpu_port.term_hash(t.encode("utf-8", "surrogateescape")) for i, t in zip(ids, e.decode(ids))}
+    got_classes = {h[ci]: (int(fi), int(ki)) for ci, fi, ki in zip(c.tolist(), f.tolist(), k.tolist()) if ki}
+    got_cc = {(h[x], h[y], h[z]): (int(r), int(d)) for x, y, z, r, d in zip(a.tolist(), p.tolist(), b.tolist(), nrows.tolist(), dist.tolist())}
+    assert got_classes == ref["measures"]["classes"]
+    assert got_cc == ref["measures"]["cc"]
     return ref
 
 
