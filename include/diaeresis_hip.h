@@ -130,7 +130,10 @@ int dx_instance_graph_fetch(dx_ctx* ctx, int64_t* vertex_terms, int64_t* edge_sr
  *   dx_measures_write     <base><dataset>_data/schema_cc/part-00000 (+ _SUCCESS) with the text lines
  *                         "((subType,pred,objType),rows,dist)" that Loader.loadCC parses (Loader.scala:318-322),
  *                         <local_dir><dataset>_local/schema_node_freq.txt and schema_node_count.txt
- *                         ("class\tvalue", descending value; Constatnts.scala:13,34,40). */
+ *                         ("class\tvalue", descending value; Constatnts.scala:13,34,40). Each of the three is
+ *                         written only if it does not exist yet, as Preprocessor.computeMeasures does (:37-46).
+ * They need no class index: dx_partition_file takes a null class_index_path (no class is placed anywhere), which is
+ * how dx-dap produces them before the schema clustering has run. */
 typedef struct dx_measure_sizes {
   uint64_t n_classes, n_cc, n_type_entries, n_cc_rows;
   double device_ms;

@@ -201,8 +201,8 @@ int dx_partition_device(dx_ctx* ctx, const void* d_text, uint64_t n_bytes, const
 int dx_partition_file(dx_ctx* ctx, const char* instances_path, const char* class_index_path, int n_partitions,
                       dx_part_stats* stats) {
   return guard(ctx, [&] {
-    if (!instances_path || !class_index_path) throw DxError(DX_E_INVAL, "null path");
-    const std::string ci = read_file(class_index_path);
+    if (!instances_path) throw DxError(DX_E_INVAL, "null path");
+    const std::string ci = class_index_path ? read_file(class_index_path) : std::string();
     std::ifstream f(instances_path, std::ios::binary | std::ios::ate);
     if (!f) throw DxError(DX_E_NOENT, std::string("cannot open ") + instances_path);
     const uint64_t n = (uint64_t)f.tellg();
@@ -484,25 +484,25 @@ int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const 
     const std::vector<std::string> cls = decode_terms(ctx, ms.class_term);
     std::map<int64_t, const std::string*> by_term;
     for (size_t i = 0; i < cls.size(); ++i) by_term[ms.class_term[i]] = &cls[i];
-    // schema_cc: what RDD[((String, String, String), Long, Long)].saveAsTextFile writes (Preprocessor.scala:261-262)
+    // schema_cc: what RDD[((String, String, String), Long, Long)].saveAsTextFile writes (Preprocessor.scala:261-262).
+    // Each of the three outputs is written only where it does not exist yet (Preprocessor.scala:37-46).
     const std::string cc = B + D + "_data/schema_cc";
     struct stat stt;
-    if (stat(cc.c_str(), &stt) == 0)  // Preprocessor.scala:37: skipped when it exists; saveAsTextFile itself refuses to overwrite
-      throw DxError(DX_E_INVAL, cc + " already exists (the reference skips the computation in that case; remove it to rewrite)");
-    mkdirs(cc);
-    {
+    if (stat(cc.c_str(), &stt) != 0) {
+      mkdirs(cc);
       const std::vector<std::string> preds = decode_terms(ctx, ms.cc_pred);
       std::ofstream f(cc + "/part-00000", std::ios::binary);
       for (size_t g = 0; g < ms.cc_rows.size(); ++g)
         f << "((" << *by_term[ms.cc_sub[g]] << "," << preds[g] << "," << *by_term[ms.cc_obj[g]] << ")," << ms.cc_rows[g] << "," << ms.cc_dist[g]
           << ")\n";
       if (!f) throw DxError(DX_E_IO, "writing " + cc + " failed");
+      touch(cc + "/_SUCCESS");
     }
-    touch(cc + "/_SUCCESS");
     // schema_node_freq.txt / schema_node_count.txt: "class\tvalue", descending value (Preprocessor.scala:321-325, 334-338);
     // equal values are ordered by class term id here (the reference leaves them in no particular order)
     mkdirs(L + D + "_local");
     auto write_sorted = [&](const std::string& path, const std::vector<int64_t>& v) {
+      if (stat(path.c_str(), &stt) == 0) return;
       std::vector<size_t> idx;
       for (size_t i = 0; i < v.size(); ++i)
         if (v[i] > 0) idx.push_back(i);  // a class that never reaches the reduceByKey has no line

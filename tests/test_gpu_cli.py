@@ -17,11 +17,24 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
     from oracle import dap_oracle, query_oracle
     ref = lubm1["oracle"]
     cwd = tmp_path
-    (cwd / "LUBM_local").mkdir()
-    (cwd / "LUBM_local" / "class_index.txt_4_bal").write_text(lubm1["class_index"])
     (cwd / "instances.nt").write_bytes(bytes(lubm1["bytes"]))
     base = str(cwd / "store")
     env = dict(os.environ)
+
+    # before the schema clustering has written a class index: the measures it needs are produced, then the tool stops
+    p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM", "4", base, str(cwd / "instances.nt"), "unused-schema-path"],
+                       cwd=cwd, capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 1 and "class_index.txt_4_bal not found" in p.stderr, p.stdout + p.stderr
+    freq = dict(ln.split("\t") for ln in (cwd / "LUBM_local" / "schema_node_freq.txt").read_text().splitlines())
+    assert {k: int(v) for k, v in freq.items()} == ref["schema_node_freq"]
+    count = dict(ln.split("\t") for ln in (cwd / "LUBM_local" / "schema_node_count.txt").read_text().splitlines())
+    assert {k: int(v) for k, v in count.items()} == ref["schema_node_count"]
+    cc = {}
+    for line in open(os.path.join(base, "LUBM_data", "schema_cc", "part-00000")):
+        x = line.rstrip("\n").split(",")  # Loader.loadCC (Loader.scala:318-322)
+        cc[(x[0][2:], x[1], x[2][:-1])] = (int(x[3]), int(x[4][:-1]))
+    assert cc == ref["schema_cc"]
+    (cwd / "LUBM_local" / "class_index.txt_4_bal").write_text(lubm1["class_index"])
 
     # wrong argument count: message and exit code of System.exit(-1)
     p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM"], cwd=cwd, capture_output=True, text=True)

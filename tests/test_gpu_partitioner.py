@@ -172,7 +172,6 @@ def test_true_hash_collision_is_detected_and_resolved(engine):
 def test_measure_files(engine, tmp_path):
     """schema_cc / schema_node_freq.txt / schema_node_count.txt as Loader.loadCC, loadSchemaNodeFreq and
     loadSchemaNodeCount read them (Loader.scala:318-322, 348-365)."""
-    from opus_amd.engine import DxError
     from oracle import dap_oracle
     text, ci, n = EDGE_CASES["repeated_types_and_empty_class"]
     engine.partition_text(text.encode(), ci, n)
@@ -190,5 +189,10 @@ def test_measure_files(engine, tmp_path):
         rows = [ln.rstrip("\n").split("\t") for ln in open(tmp_path / "ds_local" / name)]
         assert {r[0]: int(r[1]) for r in rows} == ref[key]
         assert [int(r[1]) for r in rows] == sorted((int(r[1]) for r in rows), reverse=True)
-    with pytest.raises(DxError):  # like saveAsTextFile, never over an existing directory
-        engine.write_measures(str(tmp_path), "ds", str(tmp_path))
+    # what exists is left alone (Preprocessor.scala:37-46), what is missing is written again
+    os.remove(tmp_path / "ds_local" / "schema_node_count.txt")
+    with open(tmp_path / "ds_local" / "schema_node_freq.txt", "w") as f:
+        f.write("kept\t1\n")
+    engine.write_measures(str(tmp_path), "ds", str(tmp_path))
+    assert open(tmp_path / "ds_local" / "schema_node_freq.txt").read() == "kept\t1\n"
+    assert os.path.exists(tmp_path / "ds_local" / "schema_node_count.txt")
