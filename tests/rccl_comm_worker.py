@@ -1,0 +1,61 @@
+"""Worker of test_gpu_comm_rccl.py: one rank, backend "nccl" (RCCL). Drives every callback of the
+communicator through the same C function pointers the library calls, on buffers in device memory."""
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(out_path):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from opus_amd.host.comm import TorchComm
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    comm = TorchComm()
+    c = comm.struct
+    res = {"on_device": comm.on_device, "world": comm.world}
+    u64 = ctypes.c_uint64
+
+    send = (u64 * 1)(7)
+    recv = (u64 * 1)(0)
+    res["counts_rc"] = c.exchange_counts(None, send, recv)
+    res["counts"] = int(recv[0])
+
+    for name, dtype, eb in (("i64", torch.int64, 8), ("i32", torch.int32, 4), ("u8x12", torch.uint8, 12)):
+        n = 1000
+        src = torch.arange(n * (12 if eb == 12 else 1), device="cuda").to(dtype)
+        dst = torch.zeros_like(src)
+        cnt = (u64 * 1)(n)
+        rc = c.exchange(None, src.data_ptr(), cnt, dst.data_ptr(), cnt, eb)
+        res["exchange_" + name] = [rc, bool(torch.equal(src, dst))]
+    zero = (u64 * 1)(0)
+    res["exchange_empty_rc"] = c.exchange(None, None, zero, None, zero, 8)
+
+    vals = (u64 * 2)(5, 11)
+    res["allreduce_rc"] = c.allreduce_sum(None, vals, 2)
+    res["allreduce"] = [int(vals[0]), int(vals[1])]
+
+    src = torch.arange(513, device="cuda", dtype=torch.int64)
+    dst = torch.zeros(513, device="cuda", dtype=torch.int64)
+    cnt = (u64 * 1)(513)
+    rc = c.allgather(None, src.data_ptr(), 513, dst.data_ptr(), cnt, 8)
+    res["allgather"] = [rc, bool(torch.equal(src, dst))]
+
+    for name, dtype, eb in (("u8", torch.uint8, 1), ("i64", torch.int64, 8)):
+        t = (torch.arange(300, device="cuda") % 3).to(dtype)
+        want = t.clone()
+        rc = c.allreduce_sum_dev(None, t.data_ptr(), 300, eb)
+        res["allreduce_dev_" + name] = [rc, bool(torch.equal(t, want))]
+
+    dist.barrier()
+    dist.destroy_process_group()
+    json.dump(res, open(out_path, "w"))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
