@@ -49,9 +49,10 @@ def _strip_union_parens(sql: str) -> str:
 class SqliteProcessor:
     """preloadTables + executeFinalQuery over in-memory (s, o) string tables."""
 
-    def __init__(self, vp: dict):
-        # vp: {(partition_name, '_3=<pred>'): [(s, o), ...]}
+    def __init__(self, vp: dict, column_type: str = "TEXT"):
+        # vp: {(partition_name, '_3=<pred>'): [(s, o), ...]}; column_type "INTEGER" for tables of term ids
         self.vp = vp
+        self.column_type = column_type
         self.db = sqlite3.connect(":memory:")
         self.loaded = set()
 
@@ -64,7 +65,7 @@ class SqliteProcessor:
             if rows is None:
                 raise FileNotFoundError(part)  # spark.read.load on a missing path throws
             if name not in self.loaded:
-                self.db.execute('CREATE TABLE "%s" (s TEXT, o TEXT)' % name)
+                self.db.execute('CREATE TABLE "%s" (s %s, o %s)' % (name, self.column_type, self.column_type))
                 self.db.executemany('INSERT INTO "%s" VALUES (?, ?)' % name, rows)
                 # indexes and statistics change SQLite's plan, never its answer: without them its join order
                 # for the six-pattern triangles takes minutes on a few hundred thousand rows
@@ -98,3 +99,18 @@ def run_query(vp: dict, translated_text: str):
     cols_sorted = [cols[i] for i in order]
     rows_sorted = sorted(tuple(r[i] for i in order) for r in rows)
     return {"count": len(rows), "columns": cols_sorted, "rows": rows_sorted, "load_data": loaded, "tp": tp}
+
+
+def run_query_ids(vp_ids: dict, translated_text: str, term_id):
+    """The same statement over tables of term ids (for inputs too large to decode into Python strings):
+    every quoted constant of the SQL text is replaced by term_id(constant) (-1 for a term that is not in the
+    dictionary: it then matches nothing, as the string would). Only for statements whose quoted strings are
+    all comparison constants (no projected constants). Returns {'count', 'load_data', 'tp'}."""
+    qm, partitions, tp = parse_translated_file(translated_text)
+    proc = SqliteProcessor(vp_ids, column_type="INTEGER")
+    loaded = proc.preload(partitions)
+    qm = {k: re.sub(r"'([^']*)'", lambda m: str(int(term_id(m.group(1)))), v) for k, v in qm.items()}
+    sql = _strip_union_parens(next(iter(qm.values())))
+    proc.db.execute("ANALYZE")
+    count = proc.db.execute("SELECT COUNT(*) FROM (%s)" % sql).fetchone()[0]
+    return {"count": count, "load_data": loaded, "tp": tp}
