@@ -305,6 +305,8 @@ def main():
     elapsed, part_total, total_triples = shard.combine_timings(elapsed, sum(part_s), n_triples, red_device)
     local_counts = {n: int(counts[n]) for n in qnames}
     counts = local_counts if together else shard.combine_counts(local_counts, red_device)  # together: already over all ranks
+    # the clustering's instance-scale inputs (computed once per dataset by the reference, so outside the timed step)
+    measures = None if together else eng.measures()[0]
     sharded = sharded_query_leg(args, eng, plans, qnames, local_counts, rank, world, local_rank, barrier) if (args.sharded_queries and world > 1) else None
 
     if rank == 0:
@@ -377,6 +379,9 @@ def main():
                          "traffic": traffic},
             "kernel_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kernels.items()},
         }
+        if measures is not None:
+            out["instance_measures"] = {"device_ms": measures["device_ms"], "classes": measures["n_classes"],
+                                        "cc_groups": measures["n_cc"], "cc_rows": measures["n_cc_rows"]}
         if sharded is not None:
             out["sharded_queries"] = sharded
         if not args.no_cpu_baseline:
