@@ -93,3 +93,25 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
                     assert set(rec) == {"Query", "Time", "Time_us", "Time_load", "Load_data", "Result_count", "partitions"}
                     rec = {}
     assert seen == want
+
+    # QueryProcessorCold: one query, bindings as CSV under <base><dataset>/result_cold (QueryProcessorCold.scala:28-94)
+    import csv
+    p = subprocess.run([os.path.join(BIN, "dx-query-cold"), "4"], cwd=cwd, capture_output=True, text=True)
+    assert p.returncode == 255 and p.stdout.startswith("Arguments: number of partitions, query file")
+    for name in ("Q4.txt", "Q9.txt", "Q14.txt"):
+        tr = (qdir / name).read_text()
+        qm, partitions, tp = query_oracle.parse_translated_file(tr)
+        proc = query_oracle.SqliteProcessor(ref["vp"])
+        proc.preload(partitions)
+        cols, rows = proc.execute(qm)  # columns in the order of the SELECT list, like Spark's
+        p = subprocess.run([os.path.join(BIN, "dx-query-cold"), "4", str(qdir / name), "LUBM", "1", base], cwd=cwd, capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        cold = os.path.join(base, "LUBM", "result_cold")
+        files = sorted(f for f in os.listdir(cold) if f.endswith(".csv"))
+        assert len(files) == 1 and os.path.exists(os.path.join(cold, "_SUCCESS"))  # the previous query's directory was replaced
+        with open(os.path.join(cold, files[0]), newline="") as f:
+            got = [tuple(r) for r in csv.reader(f, delimiter=",", quotechar='"', escapechar="\\", doublequote=False)]
+        assert sorted(got) == sorted(tuple(r) for r in rows), name
+        rec = dict(ln.split(": ", 1) for ln in (cwd / "results" / "LUBM" / "cold_4_bal" / ("results_%d.txt" % tp)).read_text().splitlines()[-5:])
+        assert rec["Query"] == name and int(rec["Result_count"]) == len(rows) and rec["partitions"] == ",".join(partitions)
