@@ -76,3 +76,45 @@ def test_vp_index_file(tmp_path):
     got = dict(zip(t["uri"].to_pylist(), t["parts"].to_pylist()))
     assert got == {"<a>": "o_http___x_q_,s_http___x_p_1_", "<b>": "o_http___x_q_"}
     assert len(glob.glob(os.path.join(d, "part-00000-*-c000.snappy.parquet"))) == 1
+
+
+def test_translator_command_line_over_parquet_layout(tmp_path, monkeypatch, capsys):
+    """run_translator.sh's arguments (QueryTranslator.scala:25-41) over a layout in the Scala tools' Parquet format:
+    node index and per-partition VP index read from Parquet, class index and partition statistics from
+    <dataset>_local in the working directory; one translated file per query that can be indexed."""
+    from opus_amd.host import parquet_io as P
+    from opus_amd.host import translator as T
+    T_ = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    all_terms = ["<a>", "<b>", "<A>", "<B>", "<http://x/p>", "<http://x/q>"]
+    terms = P.Terms.from_strings(all_terms)
+    base = str(tmp_path / "store") + "/"
+    P.write_node_index(base, "ds", 2, terms, np.array([0, 1]), np.array([2, 3]))       # a: A, b: B
+    for q in (0, 1):
+        P.write_vp_index(base, "ds", 2, q, terms, np.array([0, 0, 1]), np.array([0, 0, 1]), ["<http://x/p>", "<http://x/q>", "<http://x/p>"])
+    local = tmp_path / "ds_local"
+    local.mkdir()
+    (local / "class_index.txt_2_bal").write_text("<A>\t0,1\n<B>\t1\n")
+    (local / "partition_stat.txt_2_bal").write_text("00000 10\n00001 7\npart-00000-x.parquet 10\n")
+    qdir = tmp_path / "queries"
+    qdir.mkdir()
+    (qdir / "bound.txt").write_text("SELECT ?x WHERE { ?x <http://x/p> <b> . ?x %s <A> }" % T_)
+    (qdir / "varpred.txt").write_text("SELECT ?p ?y WHERE { <a> ?p ?y }")
+    (qdir / "nowhere.txt").write_text("SELECT ?x WHERE { ?x <http://x/p> <zzz> }")
+    monkeypatch.chdir(tmp_path)
+    assert T.main(["ds", "2", base[:-1]]) == 255
+    assert "-->Missing Arguments" in capsys.readouterr().out
+    assert T.main(["ds", "2", base[:-1], str(qdir)]) == 0
+    assert "Query cannot be indexed:nowhere.txt" in capsys.readouterr().out
+    out = qdir / "translated_queries_2_bal"
+    assert sorted(os.listdir(out)) == ["bound.txt", "varpred.txt"]
+    ni = {"<a>": ["<A>"], "<b>": ["<B>"]}
+    ci = T.load_class_index((local / "class_index.txt_2_bal").read_text())
+    st = T.load_partition_stats((local / "partition_stat.txt_2_bal").read_text())
+    sub = lambda part, uri: {"<a>": ["s_http___x_p_", "s_http___x_q_"], "<b>": ["o_http___x_p_"]}.get(uri, [])  # noqa: E731
+    for name in ("bound.txt", "varpred.txt"):
+        want = T.translate_query(name, (qdir / name).read_text(), lambda u: ni.get(u, []), ci, st, sub)
+        assert (out / name).read_text() == want
+    assert "UNION" in (out / "varpred.txt").read_text() and "partitions 00001-_3=_http___x_p_,00001-_3=_http___x_q_" in (out / "varpred.txt").read_text()
+    # a second run does not translate its own output
+    assert T.main(["ds", "2", base, str(qdir)]) == 0
+    assert sorted(os.listdir(out)) == ["bound.txt", "varpred.txt"]

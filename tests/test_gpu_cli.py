@@ -2,6 +2,7 @@
 process with nothing resident), results file in the reference's format."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -62,19 +63,29 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
     p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM", "4", base, str(cwd / "instances.nt"), "x"], cwd=cwd, capture_output=True, text=True)
     assert p.returncode == 0 and "nothing to do" in p.stdout
 
-    # translated queries written the way QueryTranslator.main does
+    # the translator's command line (scripts/run_translator.sh) over the layout dx-dap wrote: same arguments as
+    # QueryTranslator.main, translated files under <queries>/translated_queries_4_bal
     ni = {}
     for u, c in ref["node_index"]:
         ni.setdefault(u, []).append(c)
     ci = T.load_class_index(lubm1["class_index"])
+    (cwd / "queries").mkdir()
+    for name, text in lubm.queries(0).items():
+        (cwd / "queries" / name).write_text(text)
+    tenv = dict(env, PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-m", "opus_amd.host.translator", "LUBM", "4", base], cwd=cwd, capture_output=True, text=True, env=tenv)
+    assert p.returncode == 255 and "-->Missing Arguments" in p.stdout
+    p = subprocess.run([sys.executable, "-m", "opus_amd.host.translator", "LUBM", "4", base, str(cwd / "queries")], cwd=cwd,
+                       capture_output=True, text=True, env=tenv, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
     qdir = cwd / "queries" / "translated_queries_4_bal"
-    qdir.mkdir(parents=True)
     want = {}
     for name, text in lubm.queries(0).items():
-        if name == "Q2.txt":
-            continue  # SQLite needs seconds for this 6-way join; covered by test_gpu_queries
         tr = T.translate_query(name, text, lambda u: ni.get(u, []), ci, pstat)
-        (qdir / name).write_text(tr)
+        assert (qdir / name).read_text() == tr, name
+        if name == "Q2.txt":
+            os.remove(qdir / name)  # SQLite needs seconds for this 6-way join; covered by test_gpu_queries
+            continue
         r = query_oracle.run_query(ref["vp"], tr)
         want[name] = (r["count"], r["load_data"], r["tp"])
 
