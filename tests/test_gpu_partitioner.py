@@ -87,6 +87,11 @@ EDGE_CASES = {
         "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <B> .\n"
         "<b> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> \n<a> <p> <b> .\n<a> <p> <c> .\n<c> <q> <b> .\n<a> <p> <b> .\n<b> <q> <b> .\n",
         "<A>\t0\n<B>\t1\n", 2),
+    # more classes than one pass of the measures' per-block histogram holds (8192): the class range is walked in windows
+    "more_classes_than_a_histogram_pass": (
+        "".join("<s%d> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <C%d> .\n<s%d> <p%d> <s%d> .\n" % (i, i % 9001, i, i % 3, (i * 7 + 1) % 9500)
+                for i in range(9500)),
+        "<C1>\t0\n<C9000>\t1\n<C17>\t0,1\n", 2),
     "empty_input": ("", "<A>\t0\n", 2),
     "only_comments": ("# nothing\n# here\n", "<A>\t0\n", 2),
 }
