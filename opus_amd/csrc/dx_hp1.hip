@@ -1038,11 +1038,12 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
   eo_out[i] = eo;
 }
 
+template <typename K>  // K: the object entries' word, 32 bits when partition | term | role | predicate fit
 __global__ void __launch_bounds__(256)
 k_vpi_write(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
             const uint32_t* __restrict__ part_base, int nparts, int bits_term, int bits_pred, const uint8_t* __restrict__ es,
             const uint8_t* __restrict__ eo, const uint32_t* __restrict__ pos_s, const uint32_t* __restrict__ pos_o,
-            uint64_t* __restrict__ out_s, uint64_t* __restrict__ out_o) {
+            uint64_t* __restrict__ out_s, K* __restrict__ out_o) {
   const uint32_t total = part_base[nparts];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -1053,13 +1054,14 @@ k_vpi_write(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
   const uint64_t qq = (uint64_t)q << (bits_term + 1 + bits_pred);
   const uint32_t p = row_p[i];
   if (a) out_s[pos_s[i]] = qq | ((uint64_t)row_s[i] << (1 + bits_pred)) | p;
-  if (b) out_o[pos_o[i]] = qq | ((uint64_t)row_o[i] << (1 + bits_pred)) | (1ull << bits_pred) | p;
+  if (b) out_o[pos_o[i]] = (K)(qq | ((uint64_t)row_o[i] << (1 + bits_pred)) | (1ull << bits_pred) | p);
 }
 
 // counts (out == nullptr) or appends the (class, 'o', rdf:type) entries of the classes in use
+template <typename K>
 __global__ void __launch_bounds__(256)
 k_vpi_type_entries(const uint8_t* __restrict__ class_used, const uint64_t* __restrict__ Pm, uint32_t n_terms, uint32_t type_pidx,
-                   int bits_term, int bits_pred, unsigned long long* __restrict__ counter, uint64_t* __restrict__ out) {
+                   int bits_term, int bits_pred, unsigned long long* __restrict__ counter, K* __restrict__ out) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_terms; t += gridDim.x * blockDim.x) {
     if (!class_used[t]) continue;  // all but the class terms
     unsigned long long m = Pm[t];
@@ -1068,7 +1070,7 @@ k_vpi_type_entries(const uint8_t* __restrict__ class_used, const uint64_t* __res
     if (!out) continue;
     for (uint32_t k = 0; m; ++k, m &= m - 1) {
       const uint64_t q = (uint64_t)(__ffsll((long long)m) - 1);
-      out[at + k] = (q << (bits_term + 1 + bits_pred)) | ((uint64_t)t << (1 + bits_pred)) | (1ull << bits_pred) | type_pidx;
+      out[at + k] = (K)((q << (bits_term + 1 + bits_pred)) | ((uint64_t)t << (1 + bits_pred)) | (1ull << bits_pred) | type_pidx);
     }
   }
 }
@@ -1082,13 +1084,15 @@ __global__ void k_vpi_s_bases(const uint32_t* __restrict__ pos, const uint32_t* 
   base[q] = (q == nparts || r >= n_rows) ? *total : pos[r];
 }
 
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_flag_distinct(const uint64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ flag) {
+k_flag_distinct(const K* __restrict__ keys, uint32_t n, uint8_t* __restrict__ flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_compact_u64(const uint64_t* __restrict__ in, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n,
+k_compact_u64(const K* __restrict__ in, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n,
               uint64_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && flag[i]) out[pos[i]] = in[i];
@@ -1772,7 +1776,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     n_rec = (uint32_t)n_in;
     ps.n_uniq_slots = n_rec;
   }
-  radix_sort_u64(pool, ps.uniq.p, nullptr, n_rec, bits_pred + 2 * bits_term, s);
+  radix_sort_u64(pool, ps.uniq, n_rec, bits_pred + 2 * bits_term, s);
   tm.mark();
 
   // ---- 7. placement masks
@@ -1868,8 +1872,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
                        ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p);
     exclusive_scan_u8_u32(pool, es.p, pos_s.p, n_rows, totals.p, s);
     exclusive_scan_u8_u32(pool, eo.p, pos_o.p, n_rows, totals.p + 1, s);
-    hipLaunchKernelGGL(k_vpi_type_entries, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx, bits_term,
-                       bits_pred, n_type_ent.p, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(k_vpi_type_entries<uint64_t>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx,
+                       bits_term, bits_pred, n_type_ent.p, (uint64_t*)nullptr);
     DevBuf<uint32_t> sb(pool, nparts + 1);
     hipLaunchKernelGGL(k_vpi_s_bases, dim3(1), dim3(128), 0, s, pos_s.p, d_part_base.p, nparts, n_rows, totals.p, sb.p);
     uint32_t h_tot[2] = {0, 0};
@@ -1882,23 +1886,31 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     const uint32_t n_s = h_tot[0], n_o_raw = h_tot[1] + (uint32_t)h_type_ent;
     for (int q = 0; q <= nparts; ++q) ps.vpi_s_base[q] = hsb[q];
     ps.vpi_s = DevBuf<uint64_t>(pool, n_s);
-    DevBuf<uint64_t> ent(pool, n_o_raw);
-    hipLaunchKernelGGL(k_vpi_write, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts, bits_term,
-                       bits_pred, es.p, eo.p, pos_s.p, pos_o.p, ps.vpi_s.p, ent.p);
-    if (h_type_ent)
-      hipLaunchKernelGGL(k_vpi_type_entries, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx, bits_term,
-                         bits_pred, n_type_ent.p + 1, ent.p + h_tot[1]);
-    es.reset(); eo.reset(); pos_s.reset(); pos_o.reset();
-    radix_sort_u64(pool, ent.p, nullptr, n_o_raw, bits_for(nparts) + bits_term + 1 + bits_pred, s);
-    DevBuf<uint8_t> fl(pool, n_o_raw);
-    DevBuf<uint32_t> fp(pool, n_o_raw);
-    if (n_o_raw) hipLaunchKernelGGL(k_flag_distinct, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, n_o_raw, fl.p);
-    exclusive_scan_u8_u32(pool, fl.p, fp.p, n_o_raw, d_total.p, s);
+    // The object entries are written, sorted and made distinct in words just wide enough for them: LUBM-100 needs
+    // 31 bits (3 partition + 22 term + 1 role + 5 predicate), and half-width keys halve the traffic of the sort.
+    const int ent_bits = bits_for(nparts) + bits_term + 1 + bits_pred;
     uint32_t n_o = 0;
-    DX_HIP(hipMemcpyAsync(&n_o, d_total.p, 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
-    ps.vpi_o = DevBuf<uint64_t>(pool, n_o);
-    if (n_o_raw) hipLaunchKernelGGL(k_compact_u64, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_o_raw, ps.vpi_o.p);
+    auto object_entries = [&](auto zero) {
+      using K = decltype(zero);
+      DevBuf<K> ent(pool, n_o_raw);
+      hipLaunchKernelGGL(k_vpi_write<K>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts, bits_term,
+                         bits_pred, es.p, eo.p, pos_s.p, pos_o.p, ps.vpi_s.p, ent.p);
+      if (h_type_ent)
+        hipLaunchKernelGGL(k_vpi_type_entries<K>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx,
+                           bits_term, bits_pred, n_type_ent.p + 1, ent.p + h_tot[1]);
+      es.reset(); eo.reset(); pos_s.reset(); pos_o.reset();
+      if constexpr (sizeof(K) == 4) radix_sort_u32(pool, ent, n_o_raw, ent_bits, s);
+      else radix_sort_u64(pool, ent, n_o_raw, ent_bits, s);
+      DevBuf<uint8_t> fl(pool, n_o_raw);
+      DevBuf<uint32_t> fp(pool, n_o_raw);
+      if (n_o_raw) hipLaunchKernelGGL(k_flag_distinct<K>, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, n_o_raw, fl.p);
+      exclusive_scan_u8_u32(pool, fl.p, fp.p, n_o_raw, d_total.p, s);
+      DX_HIP(hipMemcpyAsync(&n_o, d_total.p, 4, hipMemcpyDeviceToHost, s));
+      DX_HIP(hipStreamSynchronize(s));
+      ps.vpi_o = DevBuf<uint64_t>(pool, n_o);
+      if (n_o_raw) hipLaunchKernelGGL(k_compact_u64<K>, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_o_raw, ps.vpi_o.p);
+    };
+    if (ent_bits <= 32) object_entries((uint32_t)0); else object_entries((uint64_t)0);
     DevBuf<uint32_t> vb(pool, nparts + 1);
     hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, n_o, bits_term + 1 + bits_pred, nparts, vb.p);
     std::vector<uint32_t> hvb(nparts + 1);

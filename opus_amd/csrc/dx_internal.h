@@ -75,6 +75,9 @@ void exclusive_scan_u32_u64(DevPool& pool, const uint32_t* in, uint64_t* out, si
 // Stable LSD radix sort of 64-bit keys on bits [0, key_bits); vals (u32) optional. Result ends in
 // keys/vals; tmp arrays are taken from the pool.
 void radix_sort_u64(DevPool& pool, uint64_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s);
+// Keys only, on a pool allocation: `keys` may come back as another allocation of the same size (no final copy).
+void radix_sort_u64(DevPool& pool, DevBuf<uint64_t>& keys, size_t n, int key_bits, hipStream_t s);
+void radix_sort_u32(DevPool& pool, DevBuf<uint32_t>& keys, size_t n, int key_bits, hipStream_t s);  // keys of at most 32 bits: half the traffic
 void fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 

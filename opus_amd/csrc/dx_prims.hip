@@ -146,8 +146,9 @@ constexpr int RS_KPT = 8;
 constexpr int RS_TILE = RS_THREADS * RS_KPT;
 constexpr int RS_RADIX = 256;
 
+template <typename K>
 __global__ void __launch_bounds__(RS_THREADS)
-k_rs_hist(const uint64_t* __restrict__ keys, size_t n, int shift, uint32_t* __restrict__ tile_hist, unsigned ntiles) {
+k_rs_hist(const K* __restrict__ keys, size_t n, int shift, uint32_t* __restrict__ tile_hist, unsigned ntiles) {
   __shared__ uint32_t hist[RS_RADIX];
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -161,9 +162,9 @@ k_rs_hist(const uint64_t* __restrict__ keys, size_t n, int shift, uint32_t* __re
   tile_hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-template <bool HAS_VALS>
+template <typename K, bool HAS_VALS>
 __global__ void __launch_bounds__(RS_THREADS)
-k_rs_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint64_t* __restrict__ kout,
+k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
              uint32_t* __restrict__ vout, size_t n, int shift, const uint32_t* __restrict__ tile_off, unsigned ntiles) {
   __shared__ uint32_t whist[4][RS_RADIX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -172,7 +173,7 @@ k_rs_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
   __syncthreads();
 
   const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_KPT);
-  uint64_t k[RS_KPT];
+  K k[RS_KPT];
   uint32_t v[RS_KPT];
   uint32_t rank[RS_KPT];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -223,32 +224,51 @@ k_rs_scatter(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
   }
 }
 
-void radix_sort_u64(DevPool& pool, uint64_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
+// The passes alternate between the caller's array and a scratch array of the same size. When `keys_buf` is
+// given (it must be the pool allocation `keys` points at, with n elements) and the result ends in the scratch
+// array, the two allocations change places instead of being copied (an odd number of passes over 13 M keys
+// would otherwise end with a 100 MB copy).
+template <typename K>
+static void radix_sort_impl(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
   if (n < 2 || key_bits <= 0) return;
   if (n >= (1ull << 32)) throw DxError(DX_E_RANGE, "radix_sort_u64: more than 2^32 keys");
   const unsigned ntiles = (unsigned)((n + RS_TILE - 1) / RS_TILE);
-  DevBuf<uint64_t> ktmp(pool, n);
+  DevBuf<K> ktmp(pool, keys_buf ? keys_buf->n : n);
   DevBuf<uint32_t> vtmp(pool, vals ? n : 1);
   DevBuf<uint32_t> hist(pool, (size_t)RS_RADIX * ntiles);
-  uint64_t* kin = keys; uint64_t* kout = ktmp.p;
+  K* kin = keys; K* kout = ktmp.p;
   uint32_t* vin = vals; uint32_t* vout = vtmp.p;
   const int passes = (key_bits + 7) / 8;
   for (int p = 0; p < passes; ++p) {
     const int shift = p * 8;
-    hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, hist.p, ntiles);
+    hipLaunchKernelGGL(k_rs_hist<K>, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, hist.p, ntiles);
     exclusive_scan_u32_u32(pool, hist.p, hist.p, (size_t)RS_RADIX * ntiles, nullptr, s);
     if (vals)
-      hipLaunchKernelGGL(k_rs_scatter<true>, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, ntiles);
+      hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, ntiles);
     else
-      hipLaunchKernelGGL(k_rs_scatter<false>, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, ntiles);
+      hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, ntiles);
     std::swap(kin, kout);
     std::swap(vin, vout);
   }
   DX_HIP(hipGetLastError());
   if (kin != keys) {
-    DX_HIP(hipMemcpyAsync(keys, kin, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-    if (vals) DX_HIP(hipMemcpyAsync(vals, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (keys_buf && !vals) {
+      std::swap(*keys_buf, ktmp);  // the stream is in order: the old array goes back to the pool only for later launches
+    } else {
+      DX_HIP(hipMemcpyAsync(keys, kin, n * sizeof(K), hipMemcpyDeviceToDevice, s));
+      if (vals) DX_HIP(hipMemcpyAsync(vals, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
   }
+}
+
+void radix_sort_u64(DevPool& pool, uint64_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
+  radix_sort_impl<uint64_t>(pool, keys, nullptr, vals, n, key_bits, s);
+}
+void radix_sort_u64(DevPool& pool, DevBuf<uint64_t>& keys, size_t n, int key_bits, hipStream_t s) {
+  radix_sort_impl<uint64_t>(pool, keys.p, &keys, nullptr, n, key_bits, s);
+}
+void radix_sort_u32(DevPool& pool, DevBuf<uint32_t>& keys, size_t n, int key_bits, hipStream_t s) {
+  radix_sort_impl<uint32_t>(pool, keys.p, &keys, nullptr, n, key_bits, s);
 }
 
 }  // namespace dx
