@@ -1,4 +1,6 @@
 // Device primitives: caching allocator, exclusive scans, stable LSD radix sort, fills.
+#include <algorithm>
+
 #include "dx_device.h"
 #include "dx_internal.h"
 
@@ -59,55 +61,128 @@ void fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s) {
 
 // ---- exclusive scan ----------------------------------------------------------------------------
 // Three launches: per-tile sums, one block scanning the tile sums, per-tile scan with offset.
+// A tile is 4096 items, walked as four stripes of 1024: in every stripe thread t owns the four consecutive
+// items 4t..4t+3, so a wave reads 256 (u8) or 1024 (u32) contiguous bytes per load and writes 1 KiB (u32
+// out) or 2 KiB (u64 out) of contiguous results per stripe; all loads of a tile are requested before the
+// first is used. Inside a tile the order is (stripe, wave, lane): sixteen wave totals go through LDS once.
 constexpr int SC_THREADS = 256;
-constexpr int SC_ITEMS = 8;
-constexpr int SC_TILE = SC_THREADS * SC_ITEMS;
+constexpr int SC_STRIPES = 4;
+constexpr int SC_STRIPE = SC_THREADS * 4;
+constexpr int SC_TILE = SC_STRIPE * SC_STRIPES;
 
-template <typename TIn, typename TOut>
-__global__ void __launch_bounds__(SC_THREADS) k_scan_tile_sums(const TIn* __restrict__ in, size_t n, TOut* __restrict__ sums) {
-  __shared__ TOut lds[8];
-  const size_t base = (size_t)blockIdx.x * SC_TILE + (size_t)threadIdx.x * SC_ITEMS;
-  TOut v = 0;
+__device__ __forceinline__ void load4(const uint8_t* in, size_t i, size_t n, bool aligned, uint32_t x[4]) {
+  if (aligned && i + 4 <= n) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(in + i);
+    x[0] = w & 0xFF; x[1] = (w >> 8) & 0xFF; x[2] = (w >> 16) & 0xFF; x[3] = w >> 24;
+  } else {
 #pragma unroll
-  for (int i = 0; i < SC_ITEMS; ++i)
-    if (base + i < n) v += (TOut)in[base + i];
-  TOut total;
-  (void)block_excl_scan_256<TOut>(v, lds, total);
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+    for (int k = 0; k < 4; ++k) x[k] = i + k < n ? in[i + k] : 0;
+  }
+}
+__device__ __forceinline__ void load4(const uint32_t* in, size_t i, size_t n, bool aligned, uint32_t x[4]) {
+  if (aligned && i + 4 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4*>(in + i);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = i + k < n ? in[i + k] : 0;
+  }
+}
+__device__ __forceinline__ void store4(uint32_t* out, size_t i, size_t n, bool aligned, const uint32_t y[4]) {
+  if (aligned && i + 4 <= n) {
+    *reinterpret_cast<uint4*>(out + i) = make_uint4(y[0], y[1], y[2], y[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k < n) out[i + k] = y[k];
+  }
+}
+__device__ __forceinline__ void store4(uint64_t* out, size_t i, size_t n, bool aligned, const uint64_t y[4]) {
+  if (aligned && i + 4 <= n) {
+    *reinterpret_cast<ulonglong2*>(out + i) = make_ulonglong2(y[0], y[1]);
+    *reinterpret_cast<ulonglong2*>(out + i + 2) = make_ulonglong2(y[2], y[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i + k < n) out[i + k] = y[k];
+  }
+}
+template <typename T> __device__ __forceinline__ T wave_incl_scan(T v, int lane) {
+  if constexpr (sizeof(T) == 8) return (T)wave_incl_scan_u64((uint64_t)v, lane);
+  else return (T)wave_incl_scan_u32((uint32_t)v, lane);
 }
 
+template <typename TIn, typename TOut>
+__global__ void __launch_bounds__(SC_THREADS) k_scan_tile_sums(const TIn* in, size_t n, TOut* __restrict__ sums) {
+  __shared__ TOut lds[4];
+  const bool aligned = (reinterpret_cast<uintptr_t>(in) & (4 * sizeof(TIn) - 1)) == 0;
+  const size_t tile0 = (size_t)blockIdx.x * SC_TILE + 4 * (size_t)threadIdx.x;
+  uint32_t x[SC_STRIPES][4];
+#pragma unroll
+  for (int r = 0; r < SC_STRIPES; ++r) load4(in, tile0 + (size_t)r * SC_STRIPE, n, aligned, x[r]);
+  TOut v = 0;
+#pragma unroll
+  for (int r = 0; r < SC_STRIPES; ++r) v += (TOut)x[r][0] + x[r][1] + x[r][2] + x[r][3];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const TOut incl = wave_incl_scan<TOut>(v, lane);
+  if (lane == 63) lds[w] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// One block turns the tile sums into their exclusive prefix: every thread walks a contiguous run of them.
 template <typename TOut>
 __global__ void __launch_bounds__(SC_THREADS) k_scan_sums(TOut* __restrict__ sums, size_t nb, TOut* __restrict__ total_out) {
   __shared__ TOut lds[8];
-  TOut carry = 0;
-  for (size_t base = 0; base < nb; base += SC_THREADS) {
-    const size_t i = base + threadIdx.x;
-    TOut v = i < nb ? sums[i] : 0, total;
-    TOut ex = block_excl_scan_256<TOut>(v, lds, total);
-    if (i < nb) sums[i] = carry + ex;
-    carry += total;
+  const size_t per = (nb + SC_THREADS - 1) / SC_THREADS;
+  const size_t b = std::min(nb, per * threadIdx.x), e = std::min(nb, b + per);
+  TOut v = 0;
+  for (size_t i = b; i < e; ++i) v += sums[i];
+  TOut total;
+  TOut run = block_excl_scan_256<TOut>(v, lds, total);
+  for (size_t i = b; i < e; ++i) {
+    const TOut x = sums[i];
+    sums[i] = run;
+    run += x;
   }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
+  if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
 template <typename TIn, typename TOut>
 __global__ void __launch_bounds__(SC_THREADS)
-k_scan_tiles(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n, const TOut* __restrict__ sums) {
-  __shared__ TOut lds[8];
-  const size_t base = (size_t)blockIdx.x * SC_TILE + (size_t)threadIdx.x * SC_ITEMS;
-  TOut x[SC_ITEMS];
-  TOut v = 0;
+k_scan_tiles(const TIn* in, TOut* out, size_t n, const TOut* __restrict__ sums) {  // in == out is allowed
+  __shared__ TOut lds[SC_STRIPES * 4];
+  const bool aligned_in = (reinterpret_cast<uintptr_t>(in) & (4 * sizeof(TIn) - 1)) == 0;
+  const bool aligned_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const size_t tile0 = (size_t)blockIdx.x * SC_TILE + 4 * (size_t)threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t x[SC_STRIPES][4];
 #pragma unroll
-  for (int i = 0; i < SC_ITEMS; ++i) {
-    x[i] = (base + i < n) ? (TOut)in[base + i] : 0;
-    v += x[i];
+  for (int r = 0; r < SC_STRIPES; ++r) load4(in, tile0 + (size_t)r * SC_STRIPE, n, aligned_in, x[r]);
+  TOut mine[SC_STRIPES], incl[SC_STRIPES];
+#pragma unroll
+  for (int r = 0; r < SC_STRIPES; ++r) {
+    mine[r] = (TOut)x[r][0] + x[r][1] + x[r][2] + x[r][3];
+    incl[r] = wave_incl_scan<TOut>(mine[r], lane);
+    if (lane == 63) lds[r * 4 + w] = incl[r];
   }
-  TOut total;
-  TOut ex = block_excl_scan_256<TOut>(v, lds, total) + sums[blockIdx.x];
+  __syncthreads();
+  TOut before = sums[blockIdx.x];  // everything ahead of (stripe r, wave w) in the tile's order
 #pragma unroll
-  for (int i = 0; i < SC_ITEMS; ++i) {
-    if (base + i < n) out[base + i] = ex;
-    ex += x[i];
+  for (int r = 0; r < SC_STRIPES; ++r) {
+    TOut here = before;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const TOut t = lds[r * 4 + k];
+      if (k < w) here += t;
+      before += t;
+    }
+    TOut y[4];
+    y[0] = here + incl[r] - mine[r];
+    y[1] = y[0] + x[r][0];
+    y[2] = y[1] + x[r][1];
+    y[3] = y[2] + x[r][2];
+    store4(out, tile0 + (size_t)r * SC_STRIPE, n, aligned_out, y);
   }
 }
 
