@@ -978,17 +978,41 @@ k_split_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ 
   }
 }
 
+// First-level partition of row i (rows are partition-major). The search starts from the partition of the
+// block's first row, which is the same for every lane and therefore runs on the scalar unit; a lane then
+// moves on only if its block straddles a partition boundary.
+__device__ __forceinline__ int partition_of_row(const uint32_t* __restrict__ part_base, int nparts, uint32_t i) {
+  const uint32_t first = blockIdx.x * blockDim.x;
+  int q = 0;
+  while (q + 1 < nparts && first >= part_base[q + 1]) ++q;
+  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+  return q;
+}
+
 // table_start[q * np + pidx] = first row of that table (rows are sorted by pidx inside a partition)
 __global__ void __launch_bounds__(256)
 k_table_starts(const uint32_t* __restrict__ row_p, const uint32_t* __restrict__ part_base /*nparts+1*/, int nparts, uint32_t np,
                uint32_t* __restrict__ start) {
+  // four consecutive rows per lane (one 16-byte load), grid-stride: a block per 256 rows would spend its time being launched
   const uint32_t total = part_base[nparts];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  int q = 0;
-  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
-  const uint32_t p = row_p[i];
-  if (i == part_base[q] || row_p[i - 1] != p) start[(size_t)q * np + p] = i;
+  for (uint32_t i0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i0 < total; i0 += 4 * gridDim.x * blockDim.x) {
+    uint32_t p[4];
+    if (i0 + 4 <= total) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row_p + i0);
+      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    } else {
+      for (int k = 0; k < 4; ++k) p[k] = i0 + k < total ? row_p[i0 + k] : 0;
+    }
+    uint32_t prev = i0 ? row_p[i0 - 1] : 0;
+    int q = 0;
+    while (q + 1 < nparts && i0 >= part_base[q + 1]) ++q;
+    for (int k = 0; k < 4 && i0 + k < total; ++k) {
+      const uint32_t i = i0 + k;
+      while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+      if (i == part_base[q] || prev != p[k]) start[(size_t)q * np + p[k]] = i;
+      prev = p[k];
+    }
+  }
 }
 
 // ---- 7. node index, VP index ------------------------------------------------------------------------------
@@ -1023,8 +1047,7 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
   const uint32_t total = part_base[nparts];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  int q = 0;
-  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+  const int q = partition_of_row(part_base, nparts, i);
   const uint32_t s = (uint32_t)row_s[i], o = (uint32_t)row_o[i], p = row_p[i];
   bool es = (flags[s] & kFlagNode) != 0;
   if (es && i > part_base[q] && row_p[i - 1] == p && (uint32_t)row_s[i - 1] == s) es = false;
@@ -1049,8 +1072,7 @@ k_vpi_write(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
   if (i >= total) return;
   const bool a = es[i], b = eo[i];
   if (!a && !b) return;
-  int q = 0;
-  while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+  const int q = partition_of_row(part_base, nparts, i);
   const uint64_t qq = (uint64_t)q << (bits_term + 1 + bits_pred);
   const uint32_t p = row_p[i];
   if (a) out_s[pos_s[i]] = qq | ((uint64_t)row_s[i] << (1 + bits_pred)) | p;
@@ -1825,7 +1847,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     const size_t nt = (size_t)nparts * (np ? np : 1);
     DevBuf<uint32_t> tstart(pool, nt);
     DX_HIP(hipMemsetAsync(tstart.p, 0xFF, nt * 4, s));
-    if (n_rows) hipLaunchKernelGGL(k_table_starts, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_p.p, d_part_base.p, nparts, np, tstart.p);
+    if (n_rows) hipLaunchKernelGGL(k_table_starts, dim3(std::min(blocks(n_rows, 1024), 2048u)), dim3(256), 0, s, ps.row_p.p, d_part_base.p, nparts, np, tstart.p);
     h_tstart.resize(nt);
     DX_HIP(hipMemcpyAsync(h_tstart.data(), tstart.p, nt * 4, hipMemcpyDeviceToHost, s));
     DX_HIP(hipStreamSynchronize(s));
