@@ -201,3 +201,51 @@ def test_measure_files(engine, tmp_path):
     engine.write_measures(str(tmp_path), "ds", str(tmp_path))
     assert open(tmp_path / "ds_local" / "schema_node_freq.txt").read() == "kept\t1\n"
     assert os.path.exists(tmp_path / "ds_local" / "schema_node_count.txt")
+
+
+def _fuzz_text(rng, n_lines):
+    """Lines built from adversarial pieces: runs of blanks and tabs (and VT / FF, which java's \\s splits on) between
+    the fields, CR / CRLF / LF endings, comments, non-ASCII and non-BMP characters next to the two units that are cut
+    from the object, literals with blanks and quotes, very short and very long terms (longer than the tokeniser's
+    overhang and longer than a whole tile), repeated triples."""
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    blanks = [" ", "\t", "  ", " \t ", "\x0b", "\x0c", " \x0c\t"]
+    ends = ["\n", "\r\n", "\r", "\n"]
+    subj = ["<s%d>" % i for i in range(12)] + ["<é%d>" % i for i in range(3)] + ["<\U00010400x>", "_:b1", "<" + "L" * 3000 + ">", "<" + "M" * 40000 + ">"]
+    cls = ["<A>", "<B>", "<C>", "<Ünï>", "<" + "K" * 1500 + ">"]
+    preds = ["<p%d>" % i for i in range(5)] + ["<" + "q" * 160 + ">", "<pé>"]
+    lits = ['"x"', '"two words"', '"quo\\"te"@en', '"1"^^<http://www.w3.org/2001/XMLSchema#integer>', '"été"', '"\U0001F600"', '""', '"' + "z" * 2500 + '"']
+    tails = [" .", " .", "  .", "\t.", " . ", "..", " ,"]
+    out = []
+    for _ in range(n_lines):
+        k = rng.integers(0, 10)
+        if k == 0:
+            out.append("# comment " + str(rng.integers(0, 99)) + ends[rng.integers(0, 4)])
+            continue
+        s = subj[rng.integers(0, len(subj))]
+        if k <= 3:
+            p, o = T, cls[rng.integers(0, len(cls))]
+        elif k <= 6:
+            p, o = preds[rng.integers(0, len(preds))], lits[rng.integers(0, len(lits))]
+        else:
+            p, o = preds[rng.integers(0, len(preds))], subj[rng.integers(0, len(subj))]
+        lead = " " if rng.integers(0, 12) == 0 else ""   # a line starting with a blank: an empty first field
+        line = lead + s + blanks[rng.integers(0, len(blanks))] + p + blanks[rng.integers(0, len(blanks))] + o + tails[rng.integers(0, len(tails))]
+        out.append(line + ends[rng.integers(0, 4)])
+        if rng.integers(0, 6) == 0:
+            out.append(out[-1])
+    text = "".join(out)
+    return text[:-1] if rng.integers(0, 2) and text.endswith("\n") and not text.endswith("\r\n") else text
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzzed_lines_against_oracle(engine, seed):
+    from oracle import dap_oracle
+    rng = np.random.default_rng(1000 + seed)
+    text = _fuzz_text(rng, 400)
+    ci = "<A>\t0,2\n<B>\t1\n<Ünï>\t3\n<" + "K" * 1500 + ">\t1,3\n"
+    try:
+        dap_oracle.run_dap(text, ci, 4)
+    except (ValueError, IndexError):
+        pytest.skip("this seed produced a line the reference throws on")
+    _run(engine, text, ci, 4)
