@@ -182,12 +182,17 @@ def sharded_query_leg(args, eng0, plans, qnames, want_counts, rank, world, local
             raise RuntimeError("sharded query counts differ from the single-GPU counts: %r" % bad)
         med = {n: float(np.median(times[n])) for n in qnames}
         geo = math.exp(sum(math.log(max(v, 1e-9)) for v in med.values()) / len(med))
-        return {"geomean_ms": geo, "query_ms": med, "dataset": "rank 0's block, tables owned by partition %% %d" % world,
-                "counts_equal_single_gpu": True}
-    finally:
-        barrier()
+        out = {"geomean_ms": geo, "query_ms": med, "dataset": "rank 0's block, tables owned by partition %% %d" % world,
+               "counts_equal_single_gpu": True}
+    except BaseException:
+        # a rank that fails must leave at once: waiting for the others here would keep them waiting for it
         if rank == 0:
             shutil.rmtree(base, ignore_errors=True)
+        raise
+    barrier()
+    if rank == 0:
+        shutil.rmtree(base, ignore_errors=True)
+    return out
 
 
 def main():
@@ -310,7 +315,9 @@ def main():
     counts = local_counts if together else shard.combine_counts(local_counts, red_device)  # together: already over all ranks
     # the clustering's instance-scale inputs (computed once per dataset by the reference, so outside the timed step)
     measures = None if together else eng.measures()[0]
-    sharded = sharded_query_leg(args, eng, plans, qnames, local_counts, rank, world, local_rank, barrier) if (args.sharded_queries and world > 1) else None
+    # (with --global-partition the timed queries already run over all ranks, and no rank holds all partitions to write out)
+    sharded = sharded_query_leg(args, eng, plans, qnames, local_counts, rank, world, local_rank, barrier) \
+        if (args.sharded_queries and world > 1 and not together) else None
 
     if rank == 0:
         med = lambda xs: float(np.median(xs))  # noqa: E731
