@@ -1399,13 +1399,16 @@ k_mark_terms(const int64_t* __restrict__ col, uint64_t n, uint64_t n_terms, uint
   }
 }
 __global__ void __launch_bounds__(256)
-k_count_marked(const uint8_t* __restrict__ seen, uint64_t n_terms, unsigned long long* __restrict__ out) {
+k_count_marked(const uint8_t* __restrict__ seen, uint64_t n_padded /*multiple of 16, padding bytes are zero*/, unsigned long long* __restrict__ out) {
   __shared__ uint32_t lds[8];
   uint32_t c = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_terms; i += (uint64_t)gridDim.x * blockDim.x) c += seen[i] ? 1u : 0u;
+  for (uint64_t i = 16 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x); i < n_padded; i += 16 * (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = *reinterpret_cast<const uint4*>(seen + i);  // sixteen marks at a time; a mark is the byte 1
+    c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
   uint32_t total;
   (void)block_excl_scan_256<uint32_t>(c, lds, total);
-  if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
+  if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);  // few blocks: the counter is one word in one L2 channel
 }
 
 void table_statistics(dx_ctx* ctx, CatalogTable& t) {
@@ -1415,19 +1418,21 @@ void table_statistics(dx_ctx* ctx, CatalogTable& t) {
   const uint64_t n_terms = ctx->dict.n_terms;
   DevBuf<unsigned long long> cnt(ctx->pool, 2);
   DX_HIP(hipMemsetAsync(cnt.p, 0, 16, s));
-  const unsigned g = (unsigned)std::min<uint64_t>(2048, (t.rows + 255) / 256);
+  // grids of a few hundred blocks: every block ends with one atomic on the same counter
+  const unsigned g = (unsigned)std::min<uint64_t>(256, (t.rows + 255) / 256);
   const bool sorted_s = t.slices.size() == 1;  // one slice of a partition: rows are in (s, o) order
-  DevBuf<uint8_t> seen(ctx->pool, n_terms ? n_terms : 1);
+  const uint64_t n_padded = (n_terms + 15) / 16 * 16 + 16;
+  DevBuf<uint8_t> seen(ctx->pool, n_padded);
   for (int col = 0; col < 2; ++col) {
     const int64_t* src = col == 0 ? t.s : t.o;
     if (col == 0 && sorted_s) {
       hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, (const uint64_t*)src, t.rows, cnt.p + col);
       continue;
     }
-    DX_HIP(hipMemsetAsync(seen.p, 0, n_terms ? n_terms : 1, s));
+    DX_HIP(hipMemsetAsync(seen.p, 0, n_padded, s));
     hipLaunchKernelGGL(k_mark_terms, dim3(g), dim3(256), 0, s, src, t.rows, n_terms, seen.p);
-    hipLaunchKernelGGL(k_count_marked, dim3((unsigned)std::min<uint64_t>(1024, (n_terms + 255) / 256 ? (n_terms + 255) / 256 : 1)), dim3(256), 0, s,
-                       seen.p, n_terms, cnt.p + col);
+    hipLaunchKernelGGL(k_count_marked, dim3((unsigned)std::min<uint64_t>(256, (n_padded / 16 + 255) / 256)), dim3(256), 0, s, seen.p, n_padded,
+                       cnt.p + col);
   }
   unsigned long long h[2] = {0, 0};
   DX_HIP(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, s));
