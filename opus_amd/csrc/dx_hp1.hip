@@ -1750,7 +1750,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DevBuf<unsigned long long> d_nv(pool, 1);
     DX_HIP(hipMemsetAsync(d_nv.p, 0, 8, s));
     if (n_terms)
-      hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
+      hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 256u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
     std::vector<uint32_t> hp(np);
     unsigned long long nv = 0;
     if (np) DX_HIP(hipMemcpyAsync(hp.data(), d_preds.p, (size_t)np * 4, hipMemcpyDeviceToHost, s));
@@ -1812,7 +1812,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<unsigned long long> counters(pool, 2);
   DX_HIP(hipMemsetAsync(counters.p, 0, 16, s));
   if (n_rec)
-    hipLaunchKernelGGL(k_place, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
+    hipLaunchKernelGGL(k_place, dim3(std::min(blocks(n_rec), 1024u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
                        owned, mask.p, node_flag.p, counters.p);
   tm.mark();
 

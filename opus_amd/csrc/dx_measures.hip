@@ -26,7 +26,7 @@ namespace {
 
 constexpr uint8_t kFlagLiteral = 1, kFlagEdge = 4;
 constexpr int MS_BINS = 8192;     // classes per histogram pass (32 KiB of LDS)
-constexpr unsigned MS_GRID = 1024;
+constexpr unsigned MS_GRID = 512;  // every block ends with one atomic per class it met: few blocks, or the class counters queue up
 
 inline unsigned blocks(uint64_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per ? (n + per - 1) / per : 1); }
 inline int bits_for(uint64_t n) {
