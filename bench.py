@@ -314,7 +314,7 @@ def main():
     local_counts = {n: int(counts[n]) for n in qnames}
     counts = local_counts if together else shard.combine_counts(local_counts, red_device)  # together: already over all ranks
     # the clustering's instance-scale inputs (computed once per dataset by the reference, so outside the timed step)
-    measures = None if together else eng.measures()[0]
+    measures = eng.measures()[0]  # with --global-partition a collective call: over all ranks' triples
     # (with --global-partition the timed queries already run over all ranks, and no rank holds all partitions to write out)
     sharded = sharded_query_leg(args, eng, plans, qnames, local_counts, rank, world, local_rank, barrier) \
         if (args.sharded_queries and world > 1 and not together) else None

@@ -132,6 +132,8 @@ int dx_instance_graph_fetch(dx_ctx* ctx, int64_t* vertex_terms, int64_t* edge_sr
  *                         <local_dir><dataset>_local/schema_node_freq.txt and schema_node_count.txt
  *                         ("class\tvalue", descending value; Constatnts.scala:13,34,40). Each of the three is
  *                         written only if it does not exist yet, as Preprocessor.computeMeasures does (:37-46).
+ * With a communicator set (several GPUs) dx_measures_compute is a collective call: every rank gathers all ranks' own
+ * triples and computes the same result over the whole input.
  * They need no class index: dx_partition_file takes a null class_index_path (no class is placed anywhere), which is
  * how dx-dap produces them before the schema clustering has run. */
 typedef struct dx_measure_sizes {

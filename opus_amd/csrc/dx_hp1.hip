@@ -1799,6 +1799,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     if (n_in >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 triples arrive on one GPU");
     DevBuf<uint64_t> inbox(pool, n_in);
     comm_ok(cm.exchange(cm.user, outbox.p, send.data(), inbox.p, recv.data(), 8), "exchange of the triples");
+    ps.local_keys = std::move(ps.uniq);
+    ps.n_local_keys = n_rec;
     ps.uniq = std::move(inbox);
     n_rec = (uint32_t)n_in;
     ps.n_uniq_slots = n_rec;

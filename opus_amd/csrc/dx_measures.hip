@@ -224,12 +224,33 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   const PartitionState& ps = ctx->part;
   const Dictionary& d = ctx->dict;
   if (!ps.valid || !ps.uniq.p) throw DxError(DX_E_INVAL, "the measures need the state of a partition run in this context");
-  if (ctx->comm.world > 1) throw DxError(DX_E_INVAL, "the measures run on the triples of one GPU (no communicator)");
   hipStream_t s = ctx->stream;
   DevPool& pool = ctx->pool;
   MeasureState& ms = ctx->measures;
   ms = MeasureState();
-  const uint32_t n = (uint32_t)ps.n_uniq_slots, n_terms = (uint32_t)d.n_terms;
+  // Several GPUs: the measures count every input triple once, wherever (and whether) it was placed, and a type
+  // stated on two ranks counts twice. Every rank therefore gathers all ranks' own triples -- 8 bytes apiece, 11 GB
+  // for the largest configuration, against 288 GB of HBM -- sorts them and computes the (schema-sized) result for
+  // itself: the same numbers on every rank, no partial results to merge.
+  const dx_comm& cm = ctx->comm;
+  DevBuf<uint64_t> gathered;
+  const uint64_t* keys = ps.uniq.p;
+  uint64_t n_keys = ps.n_uniq_slots;
+  if (cm.world > 1) {
+    if (!cm.allgather || !cm.exchange_counts) throw DxError(DX_E_INVAL, "the communicator lacks the collectives of the measures");
+    if (!ps.local_keys.p && ps.n_local_keys) throw DxError(DX_E_INVAL, "the partition run was not made with this communicator");
+    std::vector<uint64_t> mine(cm.world, ps.n_local_keys), counts(cm.world, 0);
+    if (cm.exchange_counts(cm.user, mine.data(), counts.data())) throw DxError(DX_E_IO, "collective failed: exchange_counts");
+    n_keys = 0;
+    for (uint64_t c : counts) n_keys += c;
+    gathered = DevBuf<uint64_t>(pool, n_keys);
+    DX_HIP(hipStreamSynchronize(s));
+    if (cm.allgather(cm.user, ps.local_keys.p, ps.n_local_keys, gathered.p, counts.data(), 8)) throw DxError(DX_E_IO, "collective failed: allgather of the triples");
+    radix_sort_u64(pool, gathered, n_keys, bits_for(ps.pred_terms.size() ? ps.pred_terms.size() : 1) + 2 * ps.bits_term, s);
+    keys = gathered.p;
+  }
+  if (n_keys >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 triples for the measures on one GPU");
+  const uint32_t n = (uint32_t)n_keys, n_terms = (uint32_t)d.n_terms;
   const int bt = ps.bits_term;
   const uint32_t np = (uint32_t)ps.pred_terms.size();
   hipEvent_t e0, e1;
@@ -258,13 +279,13 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   const uint64_t k0 = (uint64_t)ps.type_pidx << (2 * bt);
   const bool last_pred = ps.type_pidx + 1 >= np;  // the block then runs to the end of the keys
   const uint64_t k1 = last_pred ? ~0ull : (uint64_t)(ps.type_pidx + 1) << (2 * bt);
-  hipLaunchKernelGGL(k_ms_bounds, dim3(1), dim3(64), 0, s, ps.uniq.p, n, k0, k1, bounds.p);
+  hipLaunchKernelGGL(k_ms_bounds, dim3(1), dim3(64), 0, s, keys, n, k0, k1, bounds.p);
   uint32_t hb[2] = {0, 0};
   DX_HIP(hipMemcpyAsync(hb, bounds.p, 8, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
   const uint32_t tb = hb[0], nt = (last_pred ? n : hb[1]) - hb[0];
   if (!nt) { finish(); return; }
-  const uint64_t* tkeys = ps.uniq.p + tb;
+  const uint64_t* tkeys = keys + tb;
   DevBuf<uint8_t> head(pool, nt);
   DevBuf<uint32_t> pos(pool, nt), d_tot(pool, 2);
   hipLaunchKernelGGL(k_ms_heads, dim3(blocks(nt)), dim3(256), 0, s, tkeys, nt, head.p);
@@ -300,7 +321,7 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   for (uint32_t c0 = 0; c0 < n_classes; c0 += MS_BINS) {
     hipLaunchKernelGGL(k_ms_node_freq, dim3(std::min(blocks(n_ent), MS_GRID)), dim3(256), 0, s, ent_s.p, ent_c.p, ent_at.p, n_ent,
                        ps.term_flags.p, class_idx.p, c0, n_classes, freq.p);
-    hipLaunchKernelGGL(k_ms_edges, dim3(std::min(blocks(n), MS_GRID)), dim3(256), 0, s, ps.uniq.p, n, bt, ps.type_pidx, ps.term_flags.p,
+    hipLaunchKernelGGL(k_ms_edges, dim3(std::min(blocks(n), MS_GRID)), dim3(256), 0, s, keys, n, bt, ps.type_pidx, ps.term_flags.p,
                        type_off.p, ent_c.p, ent_at.p, class_idx.p, class_ok.p, c0, n_classes, count.p, c0 == 0 ? cc_rows.p : (uint32_t*)nullptr);
   }
 
@@ -326,7 +347,7 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
     const uint32_t r = (uint32_t)R;
     DevBuf<uint64_t> key(pool, r);
     DevBuf<uint32_t> w(pool, r);
-    hipLaunchKernelGGL(k_ms_cc_rows, dim3(blocks(n)), dim3(256), 0, s, ps.uniq.p, n, bt, ps.type_pidx, ps.term_flags.p, type_off.p, ent_c.p,
+    hipLaunchKernelGGL(k_ms_cc_rows, dim3(blocks(n)), dim3(256), 0, s, keys, n, bt, ps.type_pidx, ps.term_flags.p, type_off.p, ent_c.p,
                        ent_at.p, class_idx.p, class_ok.p, cc_rows.p, row_pos.p, bits_class, bits_pred, key.p, w.p);
     radix_sort_u64(pool, key.p, w.p, r, 2 * bits_class + bits_pred + bt, s);
     DevBuf<uint8_t> head_g(pool, r), head_i(pool, r);

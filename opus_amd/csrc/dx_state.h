@@ -64,6 +64,10 @@ struct PartitionState {
   // sorted distinct input triples packed as (pidx, s, o) plus what is needed to unpack them
   DevBuf<uint64_t> uniq;
   uint64_t n_uniq_slots = 0;          // length of uniq (duplicates are still in, flagged by equality with the predecessor)
+  // several GPUs: uniq holds what was routed to this rank; the rank's own triples (packed alike, ids of the common
+  // dictionary, unsorted) stay here for what needs every triple once, wherever it was placed
+  DevBuf<uint64_t> local_keys;
+  uint64_t n_local_keys = 0;
   int bits_term = 0;
   uint32_t type_pidx = kNil;
   DevBuf<uint8_t> term_flags;         // per term: bit0 = literal (starts with '"'), bit1 = vertex, bit2 = has edge

@@ -43,7 +43,13 @@ def main(out_path):
     e.set_comm(comm)
     st = e.partition_text(mine, ci, n_parts)
     art = engine_artifacts(e, measures=False)
-    share = {"rank": rank, "n_terms": int(st.n_terms), "n_unique": int(st.n_unique), "n_edges": int(st.n_edges),
+    from parity_util import engine_measures
+    meas = engine_measures(e, art["strs"])  # collective: every rank gathers all ranks' triples
+
+    def jsonable(m):
+        return {"cc": sorted([list(k), list(v)] for k, v in m["schema_cc"].items()), "freq": sorted(m["schema_node_freq"].items()),
+                "count": sorted(m["schema_node_count"].items())}
+    share = {"rank": rank, "measures": jsonable(meas), "n_terms": int(st.n_terms), "n_unique": int(st.n_unique), "n_edges": int(st.n_edges),
              "n_vertices": int(st.n_vertices), "n_triples_in": int(st.n_triples),
              "parts": [sorted(p) for p in art["parts"]], "node_index": sorted(art["node_index"]),
              "vp": sorted(("%s/%s" % k, sorted(v)) for k, v in art["vp"].items()),
@@ -59,7 +65,7 @@ def main(out_path):
         e1 = Engine(0)
         st1 = e1.partition_text(arr, ci, n_parts)
         a1 = engine_artifacts(e1)
-        alone = {"n_terms": int(st1.n_terms), "n_unique": int(st1.n_unique), "n_edges": int(st1.n_edges), "n_vertices": int(st1.n_vertices),
+        alone = {"measures": jsonable(a1), "n_terms": int(st1.n_terms), "n_unique": int(st1.n_unique), "n_edges": int(st1.n_edges), "n_vertices": int(st1.n_vertices),
                  "parts": [sorted(p) for p in a1["parts"]], "node_index": sorted(a1["node_index"]),
                  "vp": sorted(("%s/%s" % k, sorted(v)) for k, v in a1["vp"].items()),
                  "vp_index": {k: sorted((u, sorted(v)) for u, v in d.items()) for k, d in a1["vp_index"].items()}}

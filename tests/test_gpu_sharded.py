@@ -63,6 +63,9 @@ def test_two_ranks_partition_like_one(tmp_path):
         assert s["terms_head"] == shares[0]["terms_head"]             # with the same ids on every rank
         assert (s["n_unique"], s["n_edges"], s["n_vertices"]) == (shares[0]["n_unique"], shares[0]["n_edges"], shares[0]["n_vertices"])
     assert shares[0]["n_vertices"] == alone["n_vertices"]
+    assert len(alone["measures"]["cc"]) > 20
+    for s in shares:   # schema_cc, node frequency and node count over all ranks' triples, the same on every rank
+        assert s["measures"] == alone["measures"]
     assert shares[0]["n_edges"] <= alone["n_edges"] and shares[0]["n_unique"] <= alone["n_unique"]  # placed ones only
     for q, want in enumerate(alone["parts"]):
         for s in shares:
