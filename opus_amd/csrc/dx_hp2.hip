@@ -261,20 +261,31 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
         }
       }
     }
+    uint32_t hit[kRowsPerThread], nhit[kRowsPerThread];  // first matching row of the intermediate, number of matches
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
-      if (p.nkey == 0) { n += head[j] != kNil ? nI : 0u; continue; }
+      hit[j] = kNil;
+      nhit[j] = 0;
+      if (p.nkey == 0) { nhit[j] = head[j] != kNil ? nI : 0u; n += nhit[j]; continue; }
       const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
-      for (uint32_t r = head[j]; r != kNil; r = p.next[r]) n += probe_match(p, r, k0, k1) ? 1u : 0u;
+      for (uint32_t r = head[j]; r != kNil; r = p.next[r])
+        if (probe_match(p, r, k0, k1)) {
+          if (!nhit[j]) hit[j] = r;
+          ++nhit[j];
+        }
+      n += nhit[j];
     }
     if (p.count_only) { local += n; continue; }
     uint32_t before;
     unsigned long long pos = block_claim(n, p.out_count, before) + before;
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
+      if (!nhit[j]) continue;
       const int64_t k0 = p.nkey ? v[j][p.key_src[0]] : 0, k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
-      for (uint32_t r = head[j]; r != kNil; r = p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : p.next[r]) {
-        if (!probe_match(p, r, k0, k1)) continue;
+      // the usual row has one match, remembered from the counting walk; only several matches walk the chain again
+      const bool single = p.nkey != 0 && nhit[j] == 1;
+      for (uint32_t r = single ? hit[j] : head[j]; r != kNil; r = single ? kNil : (p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : p.next[r])) {
+        if (!single && !probe_match(p, r, k0, k1)) continue;
         if (pos < p.out.cap) {
           for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
           for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = v[j][p.new_src[c]];
