@@ -157,6 +157,10 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
  * entry of the `partitions` line ("00001-_3=<sanitised predicate>"): makes the table resident in HBM and
  * visible to SQL under "table" + key with '-' -> '_' and '=' -> '_E_' (:216). Memoised like dataMap (:327-337). */
 int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows);
+/* The whole `partitions` line of a translated query at once, as preloadTables takes it (QueryProcessor.scala:210-236):
+ * the tables' statistics for the planner are then gathered behind one wait instead of one per table.
+ * rows_total = sum of the rows (the reference's Load_data, duplicates in the list counted each time). */
+int dx_load_tables(dx_ctx* ctx, const char* const* partition_keys, int n_keys, uint64_t* rows_total);
 /* For tables that reach the host as strings (Parquet written by the Scala tools, decoded by the host's
  * Parquet library): installs a dictionary of n_terms distinct terms (term i = bytes[offsets[i], offsets[i+1]),
  * its id is i), replacing any dictionary and every loaded table, then tables are registered by id.

@@ -105,10 +105,10 @@ int main(int argc, char** argv) {
     uint64_t load_rows = 0;
     const auto l0 = std::chrono::steady_clock::now();
     bool ok = true;
-    for (const auto& p : partitions) {
-      uint64_t rows = 0;
-      if (dx_load_table(ctx, p.c_str(), &rows) != DX_OK) { fprintf(stderr, "dx-query: %s\n", dx_last_error(ctx)); ok = false; break; }
-      load_rows += rows;
+    {
+      std::vector<const char*> keys;
+      for (const auto& p : partitions) keys.push_back(p.c_str());
+      if (dx_load_tables(ctx, keys.data(), (int)keys.size(), &load_rows) != DX_OK) { fprintf(stderr, "dx-query: %s\n", dx_last_error(ctx)); ok = false; }
     }
     const auto load_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - l0).count();
     dx_result* r = nullptr;

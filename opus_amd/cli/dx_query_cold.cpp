@@ -108,9 +108,11 @@ int main(int argc, char** argv) {
     return 1;
   };
   if (dx_open_dataset(ctx, base.c_str(), dataset.c_str(), n) != DX_OK) return fail("open");
-  for (const auto& p : partitions) {  // preloadTables (:120)
-    uint64_t rows = 0;
-    if (dx_load_table(ctx, p.c_str(), &rows) != DX_OK) return fail("load");
+  {  // preloadTables (:120)
+    std::vector<const char*> keys;
+    for (const auto& p : partitions) keys.push_back(p.c_str());
+    uint64_t loaded = 0;
+    if (dx_load_tables(ctx, keys.data(), (int)keys.size(), &loaded) != DX_OK) return fail("load");
   }
   const auto t1 = std::chrono::steady_clock::now();
   dx_result* r = nullptr;

@@ -691,8 +691,9 @@ static void load_from_disk(dx_ctx* ctx, const std::string& key, CatalogTable& t)
   t.o = t.own_o.p;
 }
 
-int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
-  return guard(ctx, [&] {
+// Registers the table (resident slices, or column files from disk) without counting its distinct values yet.
+static CatalogTable& register_table(dx_ctx* ctx, const char* partition_key) {
+  {
     if (!partition_key) throw DxError(DX_E_INVAL, "null key");
     std::string key = partition_key;
     const std::string view = view_name(key);
@@ -735,14 +736,36 @@ int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
       it->second.o = it->second.own_o.p ? it->second.own_o.p : it->second.o;
       auto st = ctx->table_stats.find(key);  // statistics survive unloadTables: the data did not change
       if (st == ctx->table_stats.end()) {
-        table_statistics(ctx, it->second);
-        ctx->table_stats[key] = {it->second.distinct_s, it->second.distinct_o};
+        it->second.stats_pending = true;  // counted by the caller, or when a plan first asks
       } else {
         it->second.distinct_s = st->second.first;
         it->second.distinct_o = st->second.second;
       }
     }
-    if (rows) *rows = it->second.rows;
+    return it->second;
+  }
+}
+
+int dx_load_table(dx_ctx* ctx, const char* partition_key, uint64_t* rows) {
+  return guard(ctx, [&] {
+    CatalogTable& t = register_table(ctx, partition_key);
+    table_statistics(ctx, {&t});
+    if (rows) *rows = t.rows;
+  });
+}
+
+int dx_load_tables(dx_ctx* ctx, const char* const* partition_keys, int n_keys, uint64_t* rows_total) {
+  return guard(ctx, [&] {
+    if (n_keys < 0 || (n_keys && !partition_keys)) throw DxError(DX_E_INVAL, "null key list");
+    std::vector<CatalogTable*> tables;
+    uint64_t total = 0;
+    for (int i = 0; i < n_keys; ++i) {
+      CatalogTable& t = register_table(ctx, partition_keys[i]);  // std::map: references stay valid while others are added
+      tables.push_back(&t);
+      total += t.rows;
+    }
+    table_statistics(ctx, tables);  // the statistics of all of them behind one wait
+    if (rows_total) *rows_total = total;
   });
 }
 
@@ -794,8 +817,7 @@ int dx_load_table_ids(dx_ctx* ctx, const char* partition_key, const int64_t* s, 
     auto it = ctx->catalog.emplace(view, std::move(t)).first;
     it->second.s = it->second.own_s.p;
     it->second.o = it->second.own_o.p;
-    table_statistics(ctx, it->second);
-    ctx->table_stats[key] = {it->second.distinct_s, it->second.distinct_o};
+    it->second.stats_pending = true;
   });
 }
 
@@ -827,6 +849,7 @@ int dx_table_stats(dx_ctx* ctx, const char* partition_key, uint64_t out[3]) {
     if (!partition_key || !out) throw DxError(DX_E_INVAL, "null argument");
     auto it = ctx->catalog.find(view_name(partition_key));
     if (it == ctx->catalog.end()) throw DxError(DX_E_NOENT, std::string("table not loaded: ") + partition_key);
+    table_statistics(ctx, {&it->second});
     out[0] = it->second.rows; out[1] = it->second.distinct_s; out[2] = it->second.distinct_o;
   });
 }

@@ -1411,34 +1411,46 @@ k_count_marked(const uint8_t* __restrict__ seen, uint64_t n_padded /*multiple of
   if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);  // few blocks: the counter is one word in one L2 channel
 }
 
-void table_statistics(dx_ctx* ctx, CatalogTable& t) {
+void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
   hipStream_t s = ctx->stream;
-  if (t.rows == 0) { t.distinct_s = t.distinct_o = 0; return; }
+  std::vector<CatalogTable*> todo;
+  for (CatalogTable* t : tables)
+    if (t->stats_pending && std::find(todo.begin(), todo.end(), t) == todo.end()) todo.push_back(t);
+  if (todo.empty()) return;
   if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
   const uint64_t n_terms = ctx->dict.n_terms;
-  DevBuf<unsigned long long> cnt(ctx->pool, 2);
-  DX_HIP(hipMemsetAsync(cnt.p, 0, 16, s));
-  // grids of a few hundred blocks: every block ends with one atomic on the same counter
-  const unsigned g = (unsigned)std::min<uint64_t>(256, (t.rows + 255) / 256);
-  const bool sorted_s = t.slices.size() == 1;  // one slice of a partition: rows are in (s, o) order
+  DevBuf<unsigned long long> cnt(ctx->pool, 2 * todo.size());
+  DX_HIP(hipMemsetAsync(cnt.p, 0, 16 * todo.size(), s));
   const uint64_t n_padded = (n_terms + 15) / 16 * 16 + 16;
-  DevBuf<uint8_t> seen(ctx->pool, n_padded);
-  for (int col = 0; col < 2; ++col) {
-    const int64_t* src = col == 0 ? t.s : t.o;
-    if (col == 0 && sorted_s) {
-      hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, (const uint64_t*)src, t.rows, cnt.p + col);
-      continue;
+  DevBuf<uint8_t> seen(ctx->pool, n_padded);  // one map for all: the stream runs the tables one after another
+  for (size_t k = 0; k < todo.size(); ++k) {
+    const CatalogTable& t = *todo[k];
+    if (t.rows == 0) continue;
+    // grids of a few hundred blocks: every block ends with one atomic on the same counter
+    const unsigned g = (unsigned)std::min<uint64_t>(256, (t.rows + 255) / 256);
+    const bool sorted_s = t.slices.size() == 1;  // one slice of a partition: rows are in (s, o) order
+    for (int col = 0; col < 2; ++col) {
+      const int64_t* src = col == 0 ? t.s : t.o;
+      if (col == 0 && sorted_s) {
+        hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, (const uint64_t*)src, t.rows, cnt.p + 2 * k + col);
+        continue;
+      }
+      DX_HIP(hipMemsetAsync(seen.p, 0, n_padded, s));
+      hipLaunchKernelGGL(k_mark_terms, dim3(g), dim3(256), 0, s, src, t.rows, n_terms, seen.p);
+      hipLaunchKernelGGL(k_count_marked, dim3((unsigned)std::min<uint64_t>(256, (n_padded / 16 + 255) / 256)), dim3(256), 0, s, seen.p, n_padded,
+                         cnt.p + 2 * k + col);
     }
-    DX_HIP(hipMemsetAsync(seen.p, 0, n_padded, s));
-    hipLaunchKernelGGL(k_mark_terms, dim3(g), dim3(256), 0, s, src, t.rows, n_terms, seen.p);
-    hipLaunchKernelGGL(k_count_marked, dim3((unsigned)std::min<uint64_t>(256, (n_padded / 16 + 255) / 256)), dim3(256), 0, s, seen.p, n_padded,
-                       cnt.p + col);
   }
-  unsigned long long h[2] = {0, 0};
-  DX_HIP(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, s));
+  std::vector<unsigned long long> h(2 * todo.size(), 0);
+  DX_HIP(hipMemcpyAsync(h.data(), cnt.p, 16 * todo.size(), hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
-  t.distinct_s = h[0];
-  t.distinct_o = h[1];
+  for (size_t k = 0; k < todo.size(); ++k) {
+    CatalogTable& t = *todo[k];
+    t.distinct_s = h[2 * k];
+    t.distinct_o = h[2 * k + 1];
+    t.stats_pending = false;
+    if (!t.key.empty()) ctx->table_stats[t.key] = {t.distinct_s, t.distinct_o};  // survive unloadTables: the data does not change
+  }
 }
 
 namespace {

@@ -386,6 +386,17 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
     plan.select_cls.push_back(cls_of[slot_of(it.alias, it.col)]);
     plan.select_names.push_back(it.name);
   }
+  // Distinct counts only matter where there is something to order or to size: a statement over one relation
+  // never asks for them, the others get those of all their tables with one wait.
+  if (q.subs.size() > 1) {
+    std::vector<CatalogTable*> need;
+    for (const SqlSub& sub : q.subs)
+      for (const SqlArm& arm : sub.arms) {
+        auto it = ctx->catalog.find(arm.table);
+        if (it != ctx->catalog.end() && it->second.stats_pending) need.push_back(&it->second);
+      }
+    table_statistics(ctx, need);
+  }
   // relations
   std::vector<PlanRel> rels;
   size_t slot_i = 0;

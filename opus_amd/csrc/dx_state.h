@@ -86,7 +86,8 @@ struct CatalogTable {
   std::string key;      // "00001-_3=<pred>"
   std::string view;     // "table00001__3_E_<pred>"
   uint64_t rows = 0;
-  uint64_t distinct_s = 0, distinct_o = 0;  // gathered at load time, feed the join-order estimates
+  uint64_t distinct_s = 0, distinct_o = 0;  // feed the join-order estimates; counted when a plan first needs them
+  bool stats_pending = false;               // loaded, not counted yet
   // several GPUs: a table another rank holds has no rows here; the planner works on the numbers of the
   // whole table, which the host sets on every rank alike
   bool remote = false;
@@ -142,7 +143,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const s
                    int n_partitions);
 void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n, int64_t* ids_host);
 void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
-void table_statistics(dx_ctx* ctx, CatalogTable& t);  // distinct subjects / objects
+// distinct subjects / objects of every table in the list that still lacks them: all kernels queued, one wait
+void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables);
 // dx_measures.hip
 void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip

@@ -32,7 +32,7 @@ EXPORTS = [
     "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
-    "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write",
+    "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library():
         "dx_part_write_layout": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
         "dx_open_dataset": (c_int, [c_void_p, c_char_p, c_char_p, c_int]),
         "dx_load_table": (c_int, [c_void_p, c_char_p, u64p]),
+        "dx_load_tables": (c_int, [c_void_p, POINTER(c_char_p), c_int, u64p]),
         "dx_unload_all": (c_int, [c_void_p]),
         "dx_query": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_void_p)]),
         "dx_result_count": (c_uint64, [c_void_p]),
@@ -343,6 +344,14 @@ class Engine:
     def load_table(self, key: str) -> int:
         rows = c_uint64(0)
         self._check(self.lib.dx_load_table(self.ctx, key.encode(), byref(rows)))
+        return rows.value
+
+    def load_tables(self, keys) -> int:
+        """preloadTables: all tables of a `partitions` line at once; returns the rows loaded."""
+        keys = [k.encode() for k in keys]
+        arr = (c_char_p * len(keys))(*keys)
+        rows = c_uint64(0)
+        self._check(self.lib.dx_load_tables(self.ctx, arr, len(keys), byref(rows)))
         return rows.value
 
     def dictionary_load(self, data: np.ndarray, offsets: np.ndarray):
