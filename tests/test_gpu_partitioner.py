@@ -249,3 +249,36 @@ def test_fuzzed_lines_against_oracle(engine, seed):
     except (ValueError, IndexError):
         pytest.skip("this seed produced a line the reference throws on")
     _run(engine, text, ci, 4)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_control_characters_inside_and_around_fields(engine, seed):
+    """Fields made of arbitrary ASCII including NUL and the other control characters: java's split breaks only on
+    [ \\t\\n\\x0B\\f\\r], trim strips every unit <= U+0020 from the ends of a field, and a control character in the
+    middle belongs to the term."""
+    rng = np.random.default_rng(50 + seed)
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    ctrl = [chr(c) for c in (0, 1, 2, 7, 8, 0x0e, 0x1b, 0x1c, 0x1f, 0x7f)]
+    body = list("abcXYZ019<>:/#_-\"'") + ctrl
+    seps = [" ", "\t", "\x0b", "\x0c", "  ", "\t \x0c"]
+
+    def tok(n):
+        t = "".join(body[rng.integers(0, len(body))] for _ in range(n))
+        return t if t.strip("".join(chr(c) for c in range(0x21))) else "x" + t   # not empty after trim
+
+    names = [tok(int(rng.integers(1, 9))) for _ in range(25)]
+    lines = []
+    for _ in range(300):
+        s = names[rng.integers(0, len(names))]
+        k = rng.integers(0, 3)
+        if k == 0:
+            p, o = T, "<C%d>" % rng.integers(0, 4)
+        elif k == 1:
+            p, o = "<p%d>" % rng.integers(0, 3), names[rng.integers(0, len(names))]
+        else:
+            p, o = tok(int(rng.integers(1, 6))), '"' + tok(int(rng.integers(0, 10))) + " " + tok(2) + '"'
+        pad = ctrl[rng.integers(0, len(ctrl))] if rng.integers(0, 3) == 0 else ""
+        lines.append(s + pad + seps[rng.integers(0, len(seps))] + p + seps[rng.integers(0, len(seps))] + pad + o + pad + " .")
+    text = "\n".join(lines) + "\n"
+    ci = "<C0>\t0\n<C1>\t1\n<C2>\t0,1\n"
+    _run(engine, text, ci, 2)
