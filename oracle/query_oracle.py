@@ -101,11 +101,12 @@ def run_query(vp: dict, translated_text: str):
     return {"count": len(rows), "columns": cols_sorted, "rows": rows_sorted, "load_data": loaded, "tp": tp}
 
 
-def run_query_ids(vp_ids: dict, translated_text: str, term_id):
+def run_query_ids(vp_ids: dict, translated_text: str, term_id, max_rows: int = 0):
     """The same statement over tables of term ids (for inputs too large to decode into Python strings):
     every quoted constant of the SQL text is replaced by term_id(constant) (-1 for a term that is not in the
     dictionary: it then matches nothing, as the string would). Only for statements whose quoted strings are
-    all comparison constants (no projected constants). Returns {'count', 'load_data', 'tp'}."""
+    all comparison constants (no projected constants). Returns {'count', 'load_data', 'tp'} plus, for results of at
+    most max_rows rows, 'columns' and the sorted 'rows' of ids."""
     qm, partitions, tp = parse_translated_file(translated_text)
     proc = SqliteProcessor(vp_ids, column_type="INTEGER")
     loaded = proc.preload(partitions)
@@ -113,4 +114,11 @@ def run_query_ids(vp_ids: dict, translated_text: str, term_id):
     sql = _strip_union_parens(next(iter(qm.values())))
     proc.db.execute("ANALYZE")
     count = proc.db.execute("SELECT COUNT(*) FROM (%s)" % sql).fetchone()[0]
-    return {"count": count, "load_data": loaded, "tp": tp}
+    out = {"count": count, "load_data": loaded, "tp": tp}
+    if count <= max_rows:  # bindings as id tuples, columns in name order, sorted
+        cur = proc.db.execute(sql)
+        cols = [d[0] for d in cur.description]
+        order = sorted(range(len(cols)), key=lambda i: cols[i])
+        out["columns"] = [cols[i] for i in order]
+        out["rows"] = sorted(tuple(r[i] for i in order) for r in cur.fetchall())
+    return out

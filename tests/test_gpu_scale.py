@@ -192,10 +192,18 @@ def test_lubm100_queries_against_sqlite_on_ids(engine):
     nonempty = 0
     for name, text in lubm.queries(0).items():
         tr = T.translate_query(name, text, types_of, cidx, stat)
-        ref = run_query_ids(Tables(), tr, lambda x: engine.lookup([x])[0])
+        ref = run_query_ids(Tables(), tr, lambda x: engine.lookup([x])[0], max_rows=20000)
         qm, parts, _ = parse_translated_file(tr)
         engine.unload_all()
-        assert sum(engine.load_table(p) for p in parts) == ref["load_data"], name
-        assert engine.query(next(iter(qm.values()))).count == ref["count"], name
+        assert engine.load_tables(parts) == ref["load_data"], name
+        sql = next(iter(qm.values()))
+        assert engine.query(sql).count == ref["count"], name
+        if "rows" in ref:   # bindings, id for id
+            from opus_amd.engine import DX_QUERY_BINDINGS
+            res = engine.query(sql, DX_QUERY_BINDINGS)
+            order = sorted(range(len(res.columns)), key=lambda i: res.columns[i])
+            assert [res.columns[i] for i in order] == ref["columns"], name
+            assert sorted(map(tuple, res.ids()[:, order].tolist())) == ref["rows"], name
+            res.close()
         nonempty += ref["count"] > 0
     assert nonempty == 12  # Q5 is empty on LUBM data
