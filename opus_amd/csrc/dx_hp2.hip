@@ -569,8 +569,8 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
   }
   ca.off[ca.n] = off;
 
-  static thread_local QueryHostBlock* hb = nullptr;
-  if (!hb) DX_HIP(hipHostMalloc((void**)&hb, sizeof(QueryHostBlock), hipHostMallocDefault));
+  if (!ctx->q_host) DX_HIP(hipHostMalloc(&ctx->q_host, sizeof(QueryHostBlock), hipHostMallocDefault));
+  QueryHostBlock* hb = static_cast<QueryHostBlock*>(ctx->q_host);
 
   std::vector<uint64_t> caps(nsteps, 0);
   if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }

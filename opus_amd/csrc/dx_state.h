@@ -120,6 +120,7 @@ struct dx_ctx {
   // query workspace
   dx::DevBuf<uint8_t> qws;
   hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
+  void* q_host = nullptr;               // pinned block the final counters of a statement land in
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
   // several GPUs: collectives handed in by the host; world == 1 means single-GPU execution
   dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
