@@ -690,6 +690,7 @@ static void load_from_disk(dx_ctx* ctx, const std::string& key, CatalogTable& t)
   t.rows = rows;
   t.s = t.own_s.p;
   t.o = t.own_o.p;
+  t.several_sources = files.size() > 1;
 }
 
 // Registers the table (resident slices, or column files from disk) without counting its distinct values yet.
@@ -728,6 +729,7 @@ static CatalogTable& register_table(dx_ctx* ctx, const char* partition_key) {
             at += sl.rows;
           }
           t.s = t.own_s.p; t.o = t.own_o.p;
+          t.several_sources = true;
         }
       } else {
         load_from_disk(ctx, key, t);

@@ -1454,6 +1454,56 @@ void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
 }
 
 namespace {
+__global__ void __launch_bounds__(256)
+k_pack_pairs(const int64_t* __restrict__ s, const int64_t* __restrict__ o, uint64_t n, uint64_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ((uint64_t)s[i] << 32) | (uint32_t)o[i];
+}
+__global__ void __launch_bounds__(256)
+k_unpack_distinct_pairs(const uint64_t* __restrict__ in, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n,
+                        int64_t* __restrict__ s, int64_t* __restrict__ o) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  s[pos[i]] = (int64_t)(in[i] >> 32);
+  o[pos[i]] = (int64_t)(in[i] & 0xFFFFFFFFu);
+}
+}  // namespace
+
+const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t) {
+  if (!t.several_sources || t.rows < 2) return &t;
+  if (t.distinct_view) return t.distinct_view.get();
+  if (t.rows >= (1ull << 32) || ctx->dict.n_terms >= (1ull << 32)) throw DxError(DX_E_RANGE, "table too large for a distinct copy");
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  const uint32_t n = (uint32_t)t.rows;
+  DevBuf<uint64_t> keys(pool, n);
+  hipLaunchKernelGGL(k_pack_pairs, dim3(blocks(n)), dim3(256), 0, s, t.s, t.o, (uint64_t)n, keys.p);
+  radix_sort_u64(pool, keys, n, 32 + bits_for(ctx->dict.n_terms ? ctx->dict.n_terms : 1), s);
+  DevBuf<uint8_t> flag(pool, n);
+  DevBuf<uint32_t> pos(pool, n), d_total(pool, 1);
+  hipLaunchKernelGGL(k_flag_distinct<uint64_t>, dim3(blocks(n)), dim3(256), 0, s, keys.p, n, flag.p);
+  exclusive_scan_u8_u32(pool, flag.p, pos.p, n, d_total.p, s);
+  uint32_t kept = 0;
+  DX_HIP(hipMemcpyAsync(&kept, d_total.p, 4, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  auto v = std::make_unique<CatalogTable>();
+  v->key.clear();  // not a table of its own: its statistics are not kept by key
+  v->view = t.view;
+  v->rows = kept;
+  v->own_s = DevBuf<int64_t>(pool, kept);
+  v->own_o = DevBuf<int64_t>(pool, kept);
+  hipLaunchKernelGGL(k_unpack_distinct_pairs, dim3(blocks(n)), dim3(256), 0, s, keys.p, flag.p, pos.p, n, v->own_s.p, v->own_o.p);
+  DX_HIP(hipStreamSynchronize(s));
+  v->s = v->own_s.p;
+  v->o = v->own_o.p;
+  v->slices.push_back({v->s, v->o, kept});  // sorted by (s, o): the subject column can be counted by its changes
+  v->stats_pending = true;
+  v->remote = t.remote;
+  t.distinct_view = std::move(v);
+  return t.distinct_view.get();
+}
+
+namespace {
 void comm_ok(int rc, const char* what) {
   if (rc != 0) throw DxError(DX_E_IO, std::string("collective failed: ") + what);
 }

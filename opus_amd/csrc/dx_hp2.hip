@@ -393,7 +393,10 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
     for (const SqlSub& sub : q.subs)
       for (const SqlArm& arm : sub.arms) {
         auto it = ctx->catalog.find(arm.table);
-        if (it != ctx->catalog.end() && it->second.stats_pending) need.push_back(&it->second);
+        if (it == ctx->catalog.end()) continue;
+        CatalogTable* t = &it->second;
+        if (sub.arms.size() > 1) t = const_cast<CatalogTable*>(distinct_view_of(ctx, *t));  // the view is owned by its table
+        if (t->stats_pending) need.push_back(t);
       }
     table_statistics(ctx, need);
   }
@@ -419,7 +422,8 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
       auto it = ctx->catalog.find(arm.table);
       if (it == ctx->catalog.end()) throw DxError(DX_E_NOENT, "SQL: table or view not found: " + arm.table);
       PlanRel::Arm a;
-      a.t = &it->second;
+      // a UNION is a set union: rows a shared directory holds twice come out once (a plain sub-select keeps them)
+      a.t = sub.arms.size() > 1 ? distinct_view_of(ctx, it->second) : &it->second;
       if (arm.has_s) a.fs = add_const(arm.s_const, false);
       if (arm.has_o) a.fo = add_const(arm.o_const, false);
       for (int c = 0; c < r.ncols; ++c) {
@@ -427,9 +431,9 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
         if (a.src[c] == 2) a.src_ci[c] = add_const(arm.proj[c].constant, true);
       }
       r.arms.push_back(a);
-      r.rows_upper += it->second.rows;
+      r.rows_upper += a.t->rows;
       // uniform-frequency estimate from the table's row and distinct counts (gathered when it was loaded)
-      const CatalogTable& t = it->second;
+      const CatalogTable& t = *a.t;
       const double n = (double)(t.has_plan_stats ? t.plan_rows : t.rows);
       const double ds = (double)std::max<uint64_t>(t.has_plan_stats ? t.plan_distinct_s : t.distinct_s, 1),
                    dob = (double)std::max<uint64_t>(t.has_plan_stats ? t.plan_distinct_o : t.distinct_o, 1);

@@ -1,5 +1,7 @@
 // Context state: dictionary, partitioner results, table catalogue.
 #pragma once
+#include <memory>
+
 #include "dx_internal.h"
 
 namespace dx {
@@ -88,6 +90,10 @@ struct CatalogTable {
   uint64_t rows = 0;
   uint64_t distinct_s = 0, distinct_o = 0;  // feed the join-order estimates; counted when a plan first needs them
   bool stats_pending = false;               // loaded, not counted yet
+  // A directory that several predicates share (their names sanitise alike) is read as one table and can hold a
+  // row twice. Spark's UNION removes such rows, a plain sub-select keeps them: UNION arms read this copy instead.
+  bool several_sources = false;             // more than one slice / file behind the view
+  std::unique_ptr<CatalogTable> distinct_view;
   // several GPUs: a table another rank holds has no rows here; the planner works on the numbers of the
   // whole table, which the host sets on every rank alike
   bool remote = false;
@@ -146,6 +152,8 @@ void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64
 void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
 // distinct subjects / objects of every table in the list that still lacks them: all kernels queued, one wait
 void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables);
+// the table without repeated rows (built on first use), or the table itself when it has one source
+const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t);
 // dx_measures.hip
 void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip

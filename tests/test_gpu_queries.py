@@ -137,3 +137,38 @@ def test_sql_errors(loaded):
         with pytest.raises(DxError) as ei:
             e.query(bad)
         assert ei.value.code == code, bad
+
+
+def test_union_over_a_directory_shared_by_two_predicates():
+    """<http://x/P-1> and <http://x/p_1> sanitise to one directory name, so their rows are one table, and a pair stated
+    under both is in it twice. A plain sub-select keeps both rows (Spark reads both files); a UNION is a set union and
+    returns the pair once -- also across a layout on disk, where the directory holds two files."""
+    from opus_amd.engine import DX_QUERY_BINDINGS, Engine
+    from oracle.query_oracle import SqliteProcessor
+    from parity_util import engine_artifacts
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    text = ("<a> %s <A> .\n<b> %s <A> .\n<c> %s <A> .\n" % (T, T, T) +
+            "<a> <http://x/P-1> <b> .\n<a> <http://x/p_1> <b> .\n<a> <http://x/p_1> <c> .\n<b> <http://x/P-1> <c> .\n<a> <http://x/q> <c> .\n")
+    e = Engine(0)
+    try:
+        e.partition_text(text.encode(), "<A>\t0\n", 1)
+        art = engine_artifacts(e)
+        shared, other = "00000-_3=_http___x_p_1_", "00000-_3=_http___x_q_"
+        tab = lambda k: "table" + k.replace("-", "_").replace("=", "_E_")  # noqa: E731
+        plain = "SELECT tab0.y AS y FROM (SELECT o AS y FROM %s WHERE s == '<a>') AS tab0" % tab(shared)
+        union = ("SELECT tab0.p AS p,tab0.y AS y FROM ( (SELECT o AS y, '<%s>' AS p FROM %s WHERE s == '<a>')UNION"
+                 "(SELECT o AS y, '<%s>' AS p FROM %s WHERE s == '<a>') ) AS tab0" % (shared, tab(shared), other, tab(other)))
+        proc = SqliteProcessor(art["vp"])
+        proc.preload([shared, other])
+        want_plain = sorted(proc.execute({"X": plain})[1])
+        want_union = sorted(proc.execute({"X": union})[1])
+        assert want_plain == [("<b>",), ("<b>",), ("<c>",)] and len(want_union) == 3
+        assert e.load_tables([shared, other]) == 5
+        assert e.query(plain).count == 3
+        r = e.query(union, DX_QUERY_BINDINGS)
+        assert r.count == 3
+        rows, cols = r.rows()
+        assert cols == ["p", "y"] and rows == sorted(want_union)
+        r.close()
+    finally:
+        e.close()
