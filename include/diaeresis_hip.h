@@ -68,7 +68,9 @@ typedef struct dx_part_stats {
  * d_text: device pointer to n_bytes of UTF-8 text. class_index_text: contents of
  * <dataset>_local/class_index.txt_<N>_bal (host string, NUL-terminated). Results stay in HBM inside
  * ctx (replacing any earlier run) until dx_free; read them with the dx_part_* accessors, register
- * them for queries with dx_load_table, or persist them with dx_part_write_layout. */
+ * them for queries with dx_load_table, or persist them with dx_part_write_layout.
+ * Limits per GPU (DX_E_RANGE beyond them): fewer than 2^32/3 input triples, fewer than 2^32 dictionary terms, and
+ * fewer than 2^32 rows summed over the first-level partitions (a triple placed in k partitions is k rows). */
 int dx_partition_device(dx_ctx* ctx, const void* d_text, uint64_t n_bytes, const char* class_index_text,
                         int n_partitions, dx_part_stats* stats);
 /* Same, reading the instances file and the class index file from the local file system. */

@@ -865,10 +865,11 @@ __device__ __forceinline__ Unpacked unpack(uint64_t k, int bits_term) {
 __global__ void __launch_bounds__(256)
 k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
         const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, uint64_t owned /*partitions this rank keeps*/,
-        uint64_t* __restrict__ mask, uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges*/) {
-  // Grid-stride: the two counters are hit once per block at the end, and the grid is a few thousand blocks.
+        uint64_t* __restrict__ mask, uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges, 2 rows over all partitions*/) {
+  // Grid-stride: the counters are hit once per block at the end, and the grid is about a thousand blocks.
   // (Atomics of many blocks on one word are served one after another by a single L2 channel.)
   uint32_t uq = 0, ed = 0;
+  uint64_t rows = 0;  // a triple is one row in each of its partitions: the split's 32-bit positions must hold the sum
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint64_t k = keys[i];
     uint64_t m = 0;
@@ -895,6 +896,7 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
     }
     mask[i] = m;
     node_flag[i] = nf;
+    rows += (uint64_t)__popcll(m);
   }
   __shared__ uint32_t lds[8];
   uint32_t tu, te;
@@ -904,6 +906,10 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
     if (tu) atomicAdd(&counters[0], (unsigned long long)tu);
     if (te) atomicAdd(&counters[1], (unsigned long long)te);
   }
+  __shared__ uint64_t lds64[8];
+  uint64_t tr;
+  (void)block_excl_scan_256<uint64_t>(rows, lds64, tr);
+  if (threadIdx.x == 0 && tr) atomicAdd(&counters[2], (unsigned long long)tr);
 }
 
 // ---- 6. stable split by partition bit -----------------------------------------------------------------------
@@ -1873,8 +1879,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   // ---- 7. placement masks
   DevBuf<uint64_t> mask(pool, n_rec);
   DevBuf<uint8_t> node_flag(pool, n_rec);
-  DevBuf<unsigned long long> counters(pool, 2);
-  DX_HIP(hipMemsetAsync(counters.p, 0, 16, s));
+  DevBuf<unsigned long long> counters(pool, 3);
+  DX_HIP(hipMemsetAsync(counters.p, 0, 24, s));
   if (n_rec)
     hipLaunchKernelGGL(k_place, dim3(std::min(blocks(n_rec), 1024u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
                        owned, mask.p, node_flag.p, counters.p);
@@ -1889,15 +1895,20 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   std::vector<uint32_t> h_part_base(nparts + 1);
   for (int q = 0; q <= nparts; ++q)
     DX_HIP(hipMemcpyAsync(&h_part_base[q], sp_counts.p + (size_t)q * sp_tiles, 4, hipMemcpyDeviceToHost, s));
-  unsigned long long h_counters[2] = {0, 0};
-  DX_HIP(hipMemcpyAsync(h_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
+  unsigned long long h_counters[3] = {0, 0, 0};
+  DX_HIP(hipMemcpyAsync(h_counters, counters.p, 24, hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
+  // Row positions of the split are 32-bit; the scan above has already wrapped if this GPU holds more rows than that,
+  // so stop here, before anything is scattered by those positions. Under a communicator every rank learns of it.
+  uint64_t too_many_rows = h_counters[2] >= (1ull << 32) ? 1 : 0;
   if (sharded) {  // placed distinct triples / edges of the whole input, each counted by one rank
-    uint64_t v[2] = {h_counters[0], h_counters[1]};
-    comm_ok(cm.allreduce_sum(cm.user, v, 2), "allreduce_sum");
+    uint64_t v[3] = {h_counters[0], h_counters[1], too_many_rows};
+    comm_ok(cm.allreduce_sum(cm.user, v, 3), "allreduce_sum");
     h_counters[0] = v[0];
     h_counters[1] = v[1];
+    too_many_rows = v[2];
   }
+  if (too_many_rows) throw DxError(DX_E_RANGE, "more than 2^32 rows over the first-level partitions of one GPU");
   st.n_unique = h_counters[0];
   st.n_edges = h_counters[1];
   const uint32_t n_rows = h_part_base[nparts];
