@@ -71,62 +71,107 @@ __device__ __forceinline__ uint32_t flags_to_nibble(uint32_t f) {
 // it is a terminator and it is itself neither a terminator nor '#':  S = (T shifted by one byte) & ~(T | H).
 // (CR LF: the LF is a terminator, so it is not a start, and the byte after it is.) A start that is
 // itself a terminator is an empty line, on which the reference throws.
+//
+// Each wave walks 8 KiB of its tile, 1 KiB per step. The flags of the byte before a lane's chunk come
+// from the lane below (a DPP shift, no LDS); lane 0 takes them from lane 63 of the step before, and at
+// the start of the wave's stretch from one byte load.
+constexpr int LS_WAVE_BYTES = LS_TILE / (LS_THREADS / 64);  // 8 KiB
+constexpr int LS_STEPS = LS_WAVE_BYTES / 1024;
+
+struct LineCarry {
+  uint32_t t, l;  // 0x80000000 if the byte before the wave's current step is a terminator / an LF
+};
+
+// value of `v` in the lane below; lane 0 gets `first`
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t first) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /*wave shift right by 1*/, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t line_scan_chunk(const uint32_t (&w)[4], uint64_t i0, uint64_t n, LineCarry& carry,
+                                                    uint16_t* __restrict__ chunk_mask, unsigned long long* __restrict__ err) {
+  uint32_t L[4], R[4], T[4], H[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    L[d] = eq_mask(w[d], 0x0A0A0A0Au);
+    R[d] = eq_mask(w[d], 0x0D0D0D0Du);
+    H[d] = eq_mask(w[d], 0x23232323u);
+    T[d] = L[d] | R[d];
+  }
+  const uint32_t tin = from_lane_below(T[3], carry.t);
+  const uint32_t lin = from_lane_below(L[3], carry.l);
+  carry.t = (uint32_t)__builtin_amdgcn_readlane((int)T[3], 63);
+  carry.l = (uint32_t)__builtin_amdgcn_readlane((int)L[3], 63);
+  // Starts first; empty lines (a terminator right after an LF, or a CR after a CR) need two terminators in a row,
+  // so the work of telling them from CR LF is done only by lanes that see such a pair.
+  uint32_t S[4];
+  uint32_t tp = tin, pair = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);  // flags moved up by one byte, carry from the word before
+    S[d] = Tp & ~(T[d] | H[d]);
+    pair |= Tp & T[d];
+    tp = T[d];
+  }
+  uint32_t m16 = flags_to_nibble(S[0]) | (flags_to_nibble(S[1]) << 4) | (flags_to_nibble(S[2]) << 8) | (flags_to_nibble(S[3]) << 12);
+  const uint32_t keep = i0 + 16 <= n ? 0xFFFFu : (i0 < n ? ((1u << (uint32_t)(n - i0)) - 1u) : 0u);  // bytes past the end start nothing
+  m16 &= keep;
+  if (pair) {
+    uint32_t E[4];
+    uint32_t lp = lin;
+    tp = tin;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);
+      const uint32_t Lp = __builtin_amdgcn_alignbit(L[d], lp, 24);
+      E[d] = (Lp & T[d]) | ((Tp & ~Lp) & R[d]);  // LF then terminator, or CR then CR
+      tp = T[d];
+      lp = L[d];
+    }
+    const uint32_t e16 =
+        (flags_to_nibble(E[0]) | (flags_to_nibble(E[1]) << 4) | (flags_to_nibble(E[2]) << 8) | (flags_to_nibble(E[3]) << 12)) & keep;
+    if (e16) atomicMin(err, (unsigned long long)(i0 + __ffs((int)e16) - 1));
+  }
+  chunk_mask[i0 >> 4] = (uint16_t)m16;  // every chunk of every tile, so the tokeniser never reads an unwritten mask
+  return __popc(m16);
+}
+
 __global__ void __launch_bounds__(LS_THREADS)
 k_line_scan(const uint8_t* __restrict__ text, uint64_t n, uint16_t* __restrict__ chunk_mask, uint32_t* __restrict__ tile_counts,
             unsigned long long* __restrict__ err) {
   __shared__ uint32_t lds[8];
   const int lane = threadIdx.x & 63;
-  uint32_t mine = 0;
   const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
-#pragma unroll 2
-  for (int it = 0; it < LS_TILE / (LS_THREADS * 16); ++it) {
-    const uint64_t i0 = tile0 + (uint64_t)it * (LS_THREADS * 16) + (uint64_t)threadIdx.x * 16;
-    uint32_t w[4] = {0x78787878u, 0x78787878u, 0x78787878u, 0x78787878u};
-    if (i0 + 16 <= n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(text + i0);
-      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else if (i0 < n) {
-      for (int j = 0; j < 4; ++j)
-        for (int k = 0; k < 4; ++k)
-          if (i0 + j * 4 + k < n) w[j] = (w[j] & ~(0xFFu << (8 * k))) | ((uint32_t)text[i0 + j * 4 + k] << (8 * k));
-    }
-    uint32_t L[4], R[4], T[4], H[4];
+  const uint64_t wave0 = tile0 + (uint64_t)(threadIdx.x >> 6) * LS_WAVE_BYTES;
+  // the byte before the wave's stretch (the text starts as if after a line feed)
+  uint8_t pb = '\n';
+  if (wave0 != 0) pb = wave0 - 1 < n ? text[wave0 - 1] : (uint8_t)'x';
+  LineCarry carry;
+  carry.t = (pb == '\n' || pb == '\r') ? 0x80000000u : 0u;
+  carry.l = pb == '\n' ? 0x80000000u : 0u;
+  uint32_t mine = 0;
+  if (tile0 + LS_TILE <= n) {  // whole tile inside the text: all of the wave's loads go out before the first is used
+    uint4 v[LS_STEPS];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      L[d] = eq_mask(w[d], 0x0A0A0A0Au);
-      R[d] = eq_mask(w[d], 0x0D0D0D0Du);
-      H[d] = eq_mask(w[d], 0x23232323u);
-      T[d] = L[d] | R[d];
-    }
-    // terminator flag of the byte before this chunk: the previous lane's last byte, or a load at wave edges
-    uint32_t tin = __shfl_up(T[3], 1, 64);
-    uint32_t lin = __shfl_up(L[3], 1, 64);
-    if (lane == 0) {
-      const uint8_t pb = i0 == 0 ? (uint8_t)'\n' : (i0 - 1 < n ? text[i0 - 1] : (uint8_t)'x');
-      tin = (pb == '\n' || pb == '\r') ? 0x80000000u : 0u;
-      lin = pb == '\n' ? 0x80000000u : 0u;
-    }
-    uint32_t S[4], E[4];
-    uint32_t tp = tin, lp = lin;
+    for (int it = 0; it < LS_STEPS; ++it) v[it] = *reinterpret_cast<const uint4*>(text + wave0 + (uint64_t)it * 1024 + (uint64_t)lane * 16);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);  // flags moved up by one byte, carry from the word before
-      const uint32_t Lp = __builtin_amdgcn_alignbit(L[d], lp, 24);
-      S[d] = Tp & ~(T[d] | H[d]);
-      E[d] = (Lp & T[d]) | ((Tp & ~Lp) & R[d]);  // LF then terminator, or CR then CR
-      tp = T[d];
-      lp = L[d];
+    for (int it = 0; it < LS_STEPS; ++it) {
+      const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+      mine += line_scan_chunk(w, wave0 + (uint64_t)it * 1024 + (uint64_t)lane * 16, n, carry, chunk_mask, err);
     }
-    uint32_t m16 = flags_to_nibble(S[0]) | (flags_to_nibble(S[1]) << 4) | (flags_to_nibble(S[2]) << 8) | (flags_to_nibble(S[3]) << 12);
-    uint32_t e16 = flags_to_nibble(E[0]) | (flags_to_nibble(E[1]) << 4) | (flags_to_nibble(E[2]) << 8) | (flags_to_nibble(E[3]) << 12);
-    if (i0 + 16 > n) {  // bytes past the end of the text start nothing
-      const uint32_t keep = i0 < n ? ((1u << (uint32_t)(n - i0)) - 1u) : 0u;
-      m16 &= keep;
-      e16 &= keep;
+  } else {
+    for (int it = 0; it < LS_STEPS; ++it) {
+      const uint64_t i0 = wave0 + (uint64_t)it * 1024 + (uint64_t)lane * 16;
+      uint32_t w[4] = {0x78787878u, 0x78787878u, 0x78787878u, 0x78787878u};
+      if (i0 + 16 <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(text + i0);
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+      } else if (i0 < n) {
+        for (int j = 0; j < 4; ++j)
+          for (int k = 0; k < 4; ++k)
+            if (i0 + j * 4 + k < n) w[j] = (w[j] & ~(0xFFu << (8 * k))) | ((uint32_t)text[i0 + j * 4 + k] << (8 * k));
+      }
+      mine += line_scan_chunk(w, i0, n, carry, chunk_mask, err);
     }
-    if (e16) atomicMin(err, (unsigned long long)(i0 + __ffs((int)e16) - 1));
-    chunk_mask[i0 >> 4] = (uint16_t)m16;  // every chunk of every tile, so the tokeniser never reads an unwritten mask
-    mine += __popc(m16);
   }
   uint32_t total;
   (void)block_excl_scan_256<uint32_t>(mine, lds, total);
