@@ -221,17 +221,53 @@ constexpr int RS_KPT = 8;
 constexpr int RS_TILE = RS_THREADS * RS_KPT;
 constexpr int RS_RADIX = 256;
 
+// lanes of the wave whose digit equals this lane's (among the lanes with `valid`)
+__device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool valid) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1;
+    const uint64_t m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+// the RS_KPT keys of a lane, all requested before the first is used; keys past the end read as 0
+template <typename K>
+__device__ __forceinline__ void load_keys(const K* __restrict__ keys, size_t first, size_t stride, size_t n, K (&k)[RS_KPT]) {
+  if (first + (RS_KPT - 1) * stride < n) {
+#pragma unroll
+    for (int j = 0; j < RS_KPT; ++j) k[j] = keys[first + (size_t)j * stride];
+  } else {
+#pragma unroll
+    for (int j = 0; j < RS_KPT; ++j) {
+      const size_t i = first + (size_t)j * stride;
+      k[j] = i < n ? keys[i] : 0;
+    }
+  }
+}
+
+// Keys that arrive sorted by another field (the rows of one predicate, one after another) put all 64 lanes of a
+// wave on one counter, and LDS serialises those: the lanes of a wave that share a digit add their number once.
+// (Counting four tiles per block, to write the [digit][tile] matrix in 16-byte pieces, measured no faster.)
 template <typename K>
 __global__ void __launch_bounds__(RS_THREADS)
 k_rs_hist(const K* __restrict__ keys, size_t n, int shift, uint32_t* __restrict__ tile_hist, unsigned ntiles) {
   __shared__ uint32_t hist[RS_RADIX];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * RS_TILE;
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const size_t first = (size_t)blockIdx.x * RS_TILE + threadIdx.x;
+  K k[RS_KPT];
+  load_keys(keys, first, RS_THREADS, n, k);
 #pragma unroll
   for (int j = 0; j < RS_KPT; ++j) {
-    const size_t i = base + (size_t)j * RS_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 0xFF], 1u);
+    const bool valid = first + (size_t)j * RS_THREADS < n;
+    const uint32_t d = (uint32_t)(k[j] >> shift) & 0xFF;
+    const uint64_t peers = digit_peers(d, valid);
+    if (valid && (peers & lt) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
   }
   __syncthreads();
   tile_hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
@@ -252,20 +288,14 @@ k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __r
   uint32_t v[RS_KPT];
   uint32_t rank[RS_KPT];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  load_keys(kin, wbase + lane, 64, n, k);
+  if (HAS_VALS) load_keys(vin, wbase + lane, 64, n, v);
 #pragma unroll
   for (int j = 0; j < RS_KPT; ++j) {
     const size_t i = wbase + (size_t)j * 64 + lane;
     const bool valid = i < n;
-    k[j] = valid ? kin[i] : 0;
-    if (HAS_VALS) v[j] = valid ? vin[i] : 0;
     const uint32_t d = (uint32_t)(k[j] >> shift) & 0xFF;
-    uint64_t peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1;
-      const uint64_t m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
+    const uint64_t peers = digit_peers(d, valid);
     // lanes of one wave run in lockstep: every peer reads the counter before the leader bumps it
     uint32_t old = 0;
     if (valid) old = whist[w][d];
