@@ -179,6 +179,7 @@ void dx_free(dx_ctx* ctx) {
   ctx->pool.trim();
   if (ctx->q_ev0) { (void)hipEventDestroy(ctx->q_ev0); (void)hipEventDestroy(ctx->q_ev1); }
   if (ctx->q_host) (void)hipHostFree(ctx->q_host);
+  if (ctx->part_host) (void)hipHostFree(ctx->part_host);
   for (hipEvent_t e : ctx->part_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -1347,6 +1347,50 @@ hipEvent_t pooled_event(dx_ctx* ctx, size_t i) {
   }
   return ctx->part_events[i];
 }
+// Counts and other small results come back through one pinned block. A copy into pinned memory is queued on the
+// stream like a kernel; a copy into pageable memory makes the host wait for each one on its own (20-40 us apiece,
+// with the GPU idle). add() queues, sync() waits for the stream and hands the values out; collect() hands out
+// after a synchronisation that has happened anyway. The block is handed out from its start again at every
+// partition call; what does not fit is copied the slow way.
+constexpr size_t kPartHostBytes = 256 << 10;
+struct HostFetch {
+  dx_ctx* ctx;
+  struct Item { void* dst; size_t off, bytes; };
+  std::vector<Item> items;
+  explicit HostFetch(dx_ctx* c) : ctx(c) {}
+  void add(void* dst, const void* dev, size_t bytes) {
+    if (!bytes) return;
+    if (!ctx->part_host) {
+      void* p = nullptr;
+      DX_HIP(hipHostMalloc(&p, kPartHostBytes, hipHostMallocDefault));
+      ctx->part_host = static_cast<uint8_t*>(p);
+      ctx->part_host_used = 0;
+    }
+    const size_t off = (ctx->part_host_used + 15) & ~(size_t)15;
+    if (off + bytes > kPartHostBytes) {
+      DX_HIP(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      return;
+    }
+    DX_HIP(hipMemcpyAsync(ctx->part_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->part_host_used = off + bytes;
+    items.push_back({dst, off, bytes});
+  }
+  void collect() {
+    for (const Item& it : items) std::memcpy(it.dst, ctx->part_host + it.off, it.bytes);
+    items.clear();
+  }
+  void sync() {
+    DX_HIP(hipStreamSynchronize(ctx->stream));
+    collect();
+  }
+};
+
+// out[i] = in[i * stride]
+__global__ void k_pick_strided(const uint32_t* __restrict__ in, size_t stride, int n, uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[(size_t)i * stride];
+}
+
 struct StageTimer {
   dx_ctx* ctx;
   std::vector<hipEvent_t> ev;
@@ -1396,8 +1440,11 @@ void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64
   DX_HIP(hipMemcpyAsync(qo.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_lookup, dim3(blocks(n, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)n, d.seed, d.ht.p,
                      d.ht_mask, d.pool.p, d.pool_off.p, out.p);
-  DX_HIP(hipMemcpyAsync(ids_host, out.p, n * 8, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  HostFetch fetch(ctx);
+  const size_t mark = ctx->part_host_used;
+  fetch.add(ids_host, out.p, n * 8);
+  fetch.sync();
+  ctx->part_host_used = mark;  // nothing of this call is left in the block
 }
 
 static size_t utf16_units(const std::string& s) {
@@ -1677,6 +1724,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   dx_part_stats& st = ps.stats;
   st.n_bytes = n_bytes;
   StageTimer tm(ctx);
+  ctx->part_host_used = 0;
+  HostFetch fetch(ctx);
 
   // ---- 1. record starts
   const unsigned ntiles = (unsigned)((n_bytes + LS_TILE - 1) / LS_TILE);
@@ -1690,8 +1739,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipMemsetAsync(tile_counts.p + ntiles, 0, 4, s));
     hipLaunchKernelGGL(k_line_scan, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, err.p);
     exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, (size_t)ntiles + 1, d_total.p, s);
-    DX_HIP(hipMemcpyAsync(&n_rec, d_total.p, 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(&n_rec, d_total.p, 4);
+    fetch.sync();
   }
   st.n_triples = n_rec;
   tm.mark();
@@ -1730,10 +1779,10 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
     unsigned long long h_err = ~0ull;
     uint32_t h_coll[2] = {0, 0};
-    DX_HIP(hipMemcpyAsync(&h_err, err.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(h_coll, coll.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(&n_terms, d_total.p, 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(&h_err, err.p, 8);
+    fetch.add(h_coll, coll.p, 8);
+    fetch.add(&n_terms, d_total.p, 4);
+    fetch.sync();
     DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_first, e2, e3));
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
@@ -1781,8 +1830,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint64_t> d_total64(pool, 1);
   exclusive_scan_u32_u64(pool, term_len.p, d.pool_off.p, (size_t)n_terms + 1, d_total64.p, s);
   uint64_t pool_bytes = 0;
-  DX_HIP(hipMemcpyAsync(&pool_bytes, d_total64.p, 8, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(&pool_bytes, d_total64.p, 8);
+  fetch.sync();
   d.pool = DevBuf<uint8_t>(pool, pool_bytes + 16);
   if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * n_terms)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
                                   (uint64_t)n_terms, d.pool.p);
@@ -1855,8 +1904,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint32_t> pred_index(pool, (size_t)n_terms + 1);
   exclusive_scan_u8_u32(pool, is_pred, pred_index.p, n_terms, d_total.p, s);
   uint32_t np = 0;
-  DX_HIP(hipMemcpyAsync(&np, d_total.p, 4, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(&np, d_total.p, 4);
+  fetch.sync();
   st.n_predicates = np;
   {
     DevBuf<uint32_t> d_preds(pool, np ? np : 1);
@@ -1866,9 +1915,9 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
       hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 256u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
     std::vector<uint32_t> hp(np);
     unsigned long long nv = 0;
-    if (np) DX_HIP(hipMemcpyAsync(hp.data(), d_preds.p, (size_t)np * 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(&nv, d_nv.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(hp.data(), d_preds.p, (size_t)np * 4);
+    fetch.add(&nv, d_nv.p, 8);
+    fetch.sync();
     ps.pred_terms.assign(hp.begin(), hp.end());
     st.n_vertices = nv;
   }
@@ -1892,8 +1941,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
       hipLaunchKernelGGL(k_route_count, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx,
                          ps.term_flags.p, Pm.p, M.p, cm.world, owners.p, counts.p);
     std::vector<unsigned long long> h(cm.world);
-    DX_HIP(hipMemcpyAsync(h.data(), counts.p, sizeof(unsigned long long) * cm.world, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(h.data(), counts.p, sizeof(unsigned long long) * cm.world);
+    fetch.sync();
     std::vector<uint64_t> send(cm.world), recv(cm.world);
     std::vector<unsigned long long> cur(cm.world);
     unsigned long long run = 0;
@@ -1938,11 +1987,12 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   if (n_rec) hipLaunchKernelGGL(k_split_count, dim3(sp_tiles), dim3(SP_THREADS), 0, s, mask.p, n_rec, nparts, sp_counts.p, sp_tiles);
   exclusive_scan_u32_u32(pool, sp_counts.p, sp_counts.p, (size_t)nparts * sp_tiles + 1, nullptr, s);
   std::vector<uint32_t> h_part_base(nparts + 1);
-  for (int q = 0; q <= nparts; ++q)
-    DX_HIP(hipMemcpyAsync(&h_part_base[q], sp_counts.p + (size_t)q * sp_tiles, 4, hipMemcpyDeviceToHost, s));
+  DevBuf<uint32_t> d_part_base(pool, nparts + 1);  // where each partition's rows begin: column 0 of every row of the scanned matrix
+  hipLaunchKernelGGL(k_pick_strided, dim3(1), dim3(128), 0, s, sp_counts.p, (size_t)sp_tiles, nparts + 1, d_part_base.p);
+  fetch.add(h_part_base.data(), d_part_base.p, (nparts + 1) * 4);
   unsigned long long h_counters[3] = {0, 0, 0};
-  DX_HIP(hipMemcpyAsync(h_counters, counters.p, 24, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(h_counters, counters.p, 24);
+  fetch.sync();
   // Row positions of the split are 32-bit; the scan above has already wrapped if this GPU holds more rows than that,
   // so stop here, before anything is scattered by those positions. Under a communicator every rank learns of it.
   uint64_t too_many_rows = h_counters[2] >= (1ull << 32) ? 1 : 0;
@@ -1965,8 +2015,6 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   if (n_rec)
     hipLaunchKernelGGL(k_split_scatter, dim3(sp_tiles), dim3(SP_THREADS), 0, s, ps.uniq.p, mask.p, n_rec, nparts, bits_term, sp_counts.p,
                        sp_tiles, ps.row_s.p, ps.row_o.p, ps.row_p.p);
-  DevBuf<uint32_t> d_part_base(pool, nparts + 1);
-  DX_HIP(hipMemcpyAsync(d_part_base.p, h_part_base.data(), (nparts + 1) * 4, hipMemcpyHostToDevice, s));
   std::vector<uint32_t> h_tstart;
   {
     const size_t nt = (size_t)nparts * (np ? np : 1);
@@ -1974,8 +2022,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipMemsetAsync(tstart.p, 0xFF, nt * 4, s));
     if (n_rows) hipLaunchKernelGGL(k_table_starts, dim3(std::min(blocks(n_rows, 1024), 2048u)), dim3(256), 0, s, ps.row_p.p, d_part_base.p, nparts, np, tstart.p);
     h_tstart.resize(nt);
-    DX_HIP(hipMemcpyAsync(h_tstart.data(), tstart.p, nt * 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(h_tstart.data(), tstart.p, nt * 4);  // read by the host after the node index's synchronisation
   }
   tm.mark();
 
@@ -1983,8 +2030,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint32_t> node_pos(pool, n_rec);
   exclusive_scan_u8_u32(pool, node_flag.p, node_pos.p, n_rec, d_total.p, s);
   uint32_t n_node = 0;
-  DX_HIP(hipMemcpyAsync(&n_node, d_total.p, 4, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(&n_node, d_total.p, 4);
+  fetch.sync();
   ps.n_node = n_node;
   st.n_node_index = n_node;
   ps.node_s = DevBuf<int64_t>(pool, n_node);
@@ -2026,10 +2073,10 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     uint32_t h_tot[2] = {0, 0};
     unsigned long long h_type_ent = 0;
     std::vector<uint32_t> hsb(nparts + 1);
-    DX_HIP(hipMemcpyAsync(h_tot, totals.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(&h_type_ent, n_type_ent.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(hsb.data(), sb.p, (nparts + 1) * 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(h_tot, totals.p, 8);
+    fetch.add(&h_type_ent, n_type_ent.p, 8);
+    fetch.add(hsb.data(), sb.p, (nparts + 1) * 4);
+    fetch.sync();
     const uint32_t n_s = h_tot[0], n_o_raw = h_tot[1] + (uint32_t)h_type_ent;
     for (int q = 0; q <= nparts; ++q) ps.vpi_s_base[q] = hsb[q];
     ps.vpi_s = DevBuf<uint64_t>(pool, n_s);
@@ -2052,8 +2099,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
       DevBuf<uint32_t> fp(pool, n_o_raw);
       if (n_o_raw) hipLaunchKernelGGL(k_flag_distinct<K>, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, n_o_raw, fl.p);
       exclusive_scan_u8_u32(pool, fl.p, fp.p, n_o_raw, d_total.p, s);
-      DX_HIP(hipMemcpyAsync(&n_o, d_total.p, 4, hipMemcpyDeviceToHost, s));
-      DX_HIP(hipStreamSynchronize(s));
+      fetch.add(&n_o, d_total.p, 4);
+      fetch.sync();
       ps.vpi_o = DevBuf<uint64_t>(pool, n_o);
       if (n_o_raw) hipLaunchKernelGGL(k_compact_u64<K>, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_o_raw, ps.vpi_o.p);
     };
@@ -2061,8 +2108,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DevBuf<uint32_t> vb(pool, nparts + 1);
     hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, n_o, bits_term + 1 + bits_pred, nparts, vb.p);
     std::vector<uint32_t> hvb(nparts + 1);
-    DX_HIP(hipMemcpyAsync(hvb.data(), vb.p, (nparts + 1) * 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(hvb.data(), vb.p, (nparts + 1) * 4);
+    fetch.sync();
     for (int q = 0; q <= nparts; ++q) ps.vpi_o_base[q] = hvb[q];
     st.n_vp_index = (uint64_t)n_s + n_o;
   }
@@ -2083,13 +2130,13 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
       hipLaunchKernelGGL(k_term_spans, dim3(blocks(np)), dim3(256), 0, s, d_ids.p, np, d.pool_off.p, d_src.p, d_len.p);
       exclusive_scan_u32_u64(pool, d_len.p, d_off.p, (size_t)np + 1, d_tot.p, s);
       std::vector<uint64_t> off(np + 1);
-      DX_HIP(hipMemcpyAsync(off.data(), d_off.p, ((size_t)np + 1) * 8, hipMemcpyDeviceToHost, s));
-      DX_HIP(hipStreamSynchronize(s));
+      fetch.add(off.data(), d_off.p, ((size_t)np + 1) * 8);
+      fetch.sync();
       DevBuf<uint8_t> packed(pool, off[np] + 16);
       hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * np)), dim3(256), 0, s, d.pool.p, d_src.p, d_off.p, (uint64_t)np, packed.p);
       std::string bytes(off[np], '\0');
-      if (off[np]) DX_HIP(hipMemcpyAsync(&bytes[0], packed.p, off[np], hipMemcpyDeviceToHost, s));
-      DX_HIP(hipStreamSynchronize(s));
+      if (off[np]) fetch.add(&bytes[0], packed.p, off[np]);
+      fetch.sync();
       for (uint32_t i = 0; i < np; ++i) {
         ps.pred_strings.emplace_back(bytes.substr(off[i], off[i + 1] - off[i]));
         ps.pred_storage.push_back(uri_to_storage(ps.pred_strings[i]));

@@ -128,6 +128,8 @@ struct dx_ctx {
   hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
   void* q_host = nullptr;               // pinned block the final counters of a statement land in
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
+  uint8_t* part_host = nullptr;         // pinned block the partitioner's small results come back through
+  size_t part_host_used = 0;
   // several GPUs: collectives handed in by the host; world == 1 means single-GPU execution
   dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
