@@ -1870,14 +1870,17 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemsetAsync(Pm.p, 0, Pm.bytes() ? Pm.bytes() : 8, s));
   DX_HIP(hipMemsetAsync(M.p, 0, M.bytes() ? M.bytes() : 8, s));
   int64_t type_term = -1;
+  std::vector<int64_t> class_ids;     // these two are copied to the device from where they lie: they stay until
+  std::vector<uint64_t> class_masks;  // the stream has been synchronised again (the predicate count below)
   {
     std::string bytes;
     std::vector<uint64_t> offs{0};
-    std::vector<uint64_t> masks;
+    std::vector<uint64_t>& masks = class_masks;
     for (auto& c : classes) { bytes += c.uri; offs.push_back(bytes.size()); masks.push_back(c.mask); }
     bytes += "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>";
     offs.push_back(bytes.size());
-    std::vector<int64_t> ids(offs.size() - 1);
+    std::vector<int64_t>& ids = class_ids;
+    ids.resize(offs.size() - 1);
     dict_lookup(ctx, bytes.data(), offs.data(), ids.size(), ids.data());
     type_term = ids.back();
     if (!classes.empty() && n_terms) {
@@ -1886,7 +1889,6 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
       DX_HIP(hipMemcpyAsync(dids.p, ids.data(), classes.size() * 8, hipMemcpyHostToDevice, s));
       DX_HIP(hipMemcpyAsync(dmask.p, masks.data(), classes.size() * 8, hipMemcpyHostToDevice, s));
       hipLaunchKernelGGL(k_set_class_masks, dim3(blocks(classes.size())), dim3(256), 0, s, dids.p, dmask.p, (uint32_t)classes.size(), Pm.p);
-      DX_HIP(hipStreamSynchronize(s));  // ids/masks vectors go out of scope
     }
   }
   if (n_rec) hipLaunchKernelGGL(k_vertex_masks, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, O.p, kind.p, n_rec, Pm.p, M.p);
@@ -1920,6 +1922,22 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     fetch.sync();
     ps.pred_terms.assign(hp.begin(), hp.end());
     st.n_vertices = nv;
+  }
+  // The predicates' strings are wanted by the host at the very end. Their lengths are gathered now and their bytes
+  // packed after the split, so that both come back with synchronisations that happen anyway (a schema with ten
+  // thousand predicates would otherwise queue twenty thousand small copies, or wait twice more).
+  const std::vector<uint32_t> pred_ids32(ps.pred_terms.begin(), ps.pred_terms.end());
+  std::vector<uint64_t> pred_off((size_t)np + 1, 0);
+  std::string pred_bytes;
+  DevBuf<uint64_t> d_pred_src(pool, np), d_pred_off(pool, (size_t)np + 1);
+  if (np) {
+    DevBuf<uint32_t> d_ids(pool, np), d_len(pool, (size_t)np + 1);
+    DevBuf<uint64_t> d_tot(pool, 1);
+    DX_HIP(hipMemcpyAsync(d_ids.p, pred_ids32.data(), (size_t)np * 4, hipMemcpyHostToDevice, s));
+    DX_HIP(hipMemsetAsync(d_len.p + np, 0, 4, s));
+    hipLaunchKernelGGL(k_term_spans, dim3(blocks(np)), dim3(256), 0, s, d_ids.p, np, d.pool_off.p, d_pred_src.p, d_len.p);
+    exclusive_scan_u32_u64(pool, d_len.p, d_pred_off.p, (size_t)np + 1, d_tot.p, s);
+    fetch.add(pred_off.data(), d_pred_off.p, ((size_t)np + 1) * 8);
   }
   const int bits_term = bits_for(n_terms ? n_terms : 1), bits_pred = bits_for(np ? np : 1);
   if (bits_pred + 2 * bits_term > 64 || bits_for(nparts) + bits_term + 1 + bits_pred > 64)
@@ -1992,6 +2010,11 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   fetch.add(h_part_base.data(), d_part_base.p, (nparts + 1) * 4);
   unsigned long long h_counters[3] = {0, 0, 0};
   fetch.add(h_counters, counters.p, 24);
+  // the node index's positions do not depend on the split: their count comes back with the same synchronisation
+  DevBuf<uint32_t> node_pos(pool, n_rec);
+  exclusive_scan_u8_u32(pool, node_flag.p, node_pos.p, n_rec, d_total.p, s);
+  uint32_t n_node = 0;
+  fetch.add(&n_node, d_total.p, 4);
   fetch.sync();
   // Row positions of the split are 32-bit; the scan above has already wrapped if this GPU holds more rows than that,
   // so stop here, before anything is scattered by those positions. Under a communicator every rank learns of it.
@@ -2015,6 +2038,12 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   if (n_rec)
     hipLaunchKernelGGL(k_split_scatter, dim3(sp_tiles), dim3(SP_THREADS), 0, s, ps.uniq.p, mask.p, n_rec, nparts, bits_term, sp_counts.p,
                        sp_tiles, ps.row_s.p, ps.row_o.p, ps.row_p.p);
+  if (np && pred_off[np]) {
+    DevBuf<uint8_t> packed(pool, pred_off[np] + 16);
+    hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * np)), dim3(256), 0, s, d.pool.p, d_pred_src.p, d_pred_off.p, (uint64_t)np, packed.p);
+    pred_bytes.resize(pred_off[np]);
+    fetch.add(&pred_bytes[0], packed.p, pred_off[np]);
+  }
   std::vector<uint32_t> h_tstart;
   {
     const size_t nt = (size_t)nparts * (np ? np : 1);
@@ -2022,16 +2051,11 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     DX_HIP(hipMemsetAsync(tstart.p, 0xFF, nt * 4, s));
     if (n_rows) hipLaunchKernelGGL(k_table_starts, dim3(std::min(blocks(n_rows, 1024), 2048u)), dim3(256), 0, s, ps.row_p.p, d_part_base.p, nparts, np, tstart.p);
     h_tstart.resize(nt);
-    fetch.add(h_tstart.data(), tstart.p, nt * 4);  // read by the host after the node index's synchronisation
+    fetch.add(h_tstart.data(), tstart.p, nt * 4);  // wanted at the very end: comes back with a later synchronisation
   }
   tm.mark();
 
   // ---- 9. node index
-  DevBuf<uint32_t> node_pos(pool, n_rec);
-  exclusive_scan_u8_u32(pool, node_flag.p, node_pos.p, n_rec, d_total.p, s);
-  uint32_t n_node = 0;
-  fetch.add(&n_node, d_total.p, 4);
-  fetch.sync();
   ps.n_node = n_node;
   st.n_node_index = n_node;
   ps.node_s = DevBuf<int64_t>(pool, n_node);
@@ -2054,6 +2078,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   ps.vpi_bits_pred = bits_pred;
   ps.vpi_s_base.assign(nparts + 1, 0);
   ps.vpi_o_base.assign(nparts + 1, 0);
+  std::vector<uint32_t> hvb(nparts + 1, 0);
   if (n_rows) {
     DevBuf<uint8_t> es(pool, n_rows), eo(pool, n_rows);
     DevBuf<uint32_t> pos_s(pool, n_rows), pos_o(pool, n_rows);
@@ -2107,40 +2132,20 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     if (ent_bits <= 32) object_entries((uint32_t)0); else object_entries((uint64_t)0);
     DevBuf<uint32_t> vb(pool, nparts + 1);
     hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, n_o, bits_term + 1 + bits_pred, nparts, vb.p);
-    std::vector<uint32_t> hvb(nparts + 1);
     fetch.add(hvb.data(), vb.p, (nparts + 1) * 4);
-    fetch.sync();
-    for (int q = 0; q <= nparts; ++q) ps.vpi_o_base[q] = hvb[q];
     st.n_vp_index = (uint64_t)n_s + n_o;
   }
   tm.mark();
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.sync();
   DX_HIP(hipGetLastError());
+  if (n_rows)
+    for (int q = 0; q <= nparts; ++q) ps.vpi_o_base[q] = hvb[q];
 
   // ---- host-side catalogue of tables
   {
-    if (np) {
-      // predicate strings: lengths gathered on the device, bytes packed on the device, two copies in all
-      // (a schema with ten thousand predicates would otherwise queue twenty thousand small copies)
-      DevBuf<uint32_t> d_ids(pool, np), d_len(pool, (size_t)np + 1);
-      DevBuf<uint64_t> d_src(pool, np), d_off(pool, (size_t)np + 1), d_tot(pool, 1);
-      const std::vector<uint32_t> ids32(ps.pred_terms.begin(), ps.pred_terms.end());
-      DX_HIP(hipMemcpyAsync(d_ids.p, ids32.data(), (size_t)np * 4, hipMemcpyHostToDevice, s));
-      DX_HIP(hipMemsetAsync(d_len.p + np, 0, 4, s));
-      hipLaunchKernelGGL(k_term_spans, dim3(blocks(np)), dim3(256), 0, s, d_ids.p, np, d.pool_off.p, d_src.p, d_len.p);
-      exclusive_scan_u32_u64(pool, d_len.p, d_off.p, (size_t)np + 1, d_tot.p, s);
-      std::vector<uint64_t> off(np + 1);
-      fetch.add(off.data(), d_off.p, ((size_t)np + 1) * 8);
-      fetch.sync();
-      DevBuf<uint8_t> packed(pool, off[np] + 16);
-      hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * np)), dim3(256), 0, s, d.pool.p, d_src.p, d_off.p, (uint64_t)np, packed.p);
-      std::string bytes(off[np], '\0');
-      if (off[np]) fetch.add(&bytes[0], packed.p, off[np]);
-      fetch.sync();
-      for (uint32_t i = 0; i < np; ++i) {
-        ps.pred_strings.emplace_back(bytes.substr(off[i], off[i + 1] - off[i]));
-        ps.pred_storage.push_back(uri_to_storage(ps.pred_strings[i]));
-      }
+    for (uint32_t i = 0; i < np; ++i) {
+      ps.pred_strings.emplace_back(pred_bytes.substr(pred_off[i], pred_off[i + 1] - pred_off[i]));
+      ps.pred_storage.push_back(uri_to_storage(ps.pred_strings[i]));
     }
     std::vector<uint8_t> pred_in_layout(np);
     for (uint32_t p = 0; p < np; ++p) pred_in_layout[p] = utf16_units(ps.pred_strings[p]) < 150;  // DAP.scala:434
