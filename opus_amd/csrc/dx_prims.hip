@@ -60,7 +60,8 @@ void fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s) {
 }
 
 // ---- exclusive scan ----------------------------------------------------------------------------
-// Three launches: per-tile sums, one block scanning the tile sums, per-tile scan with offset.
+// Three launches: per-tile sums, one block scanning the tile sums, per-tile scan with offset (two launches up to
+// a thousand tiles, see k_scan_tiles).
 // A tile is 4096 items, walked as four stripes of 1024: in every stripe thread t owns the four consecutive
 // items 4t..4t+3, so a wave reads 256 (u8) or 1024 (u32) contiguous bytes per load and writes 1 KiB (u32
 // out) or 2 KiB (u64 out) of contiguous results per stripe; all loads of a tile are requested before the
@@ -69,6 +70,7 @@ constexpr int SC_THREADS = 256;
 constexpr int SC_STRIPES = 4;
 constexpr int SC_STRIPE = SC_THREADS * 4;
 constexpr int SC_TILE = SC_STRIPE * SC_STRIPES;
+constexpr size_t SC_FUSED_TILES = 1024;  // up to 4 M items
 
 __device__ __forceinline__ void load4(const uint8_t* in, size_t i, size_t n, bool aligned, uint32_t x[4]) {
   if (aligned && i + 4 <= n) {
@@ -148,10 +150,13 @@ __global__ void __launch_bounds__(SC_THREADS) k_scan_sums(TOut* __restrict__ sum
   if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
-template <typename TIn, typename TOut>
+// RAW_SUMS: `sums` still holds the tiles' own sums and every block adds up the ones before it itself (for up to a
+// thousand tiles that is four loads per thread, and one launch fewer per scan); the last block writes the total.
+template <typename TIn, typename TOut, bool RAW_SUMS>
 __global__ void __launch_bounds__(SC_THREADS)
-k_scan_tiles(const TIn* in, TOut* out, size_t n, const TOut* __restrict__ sums) {  // in == out is allowed
+k_scan_tiles(const TIn* in, TOut* out, size_t n, const TOut* __restrict__ sums, TOut* __restrict__ total_out) {  // in == out is allowed
   __shared__ TOut lds[SC_STRIPES * 4];
+  __shared__ TOut lds_before[4];
   const bool aligned_in = (reinterpret_cast<uintptr_t>(in) & (4 * sizeof(TIn) - 1)) == 0;
   const bool aligned_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   const size_t tile0 = (size_t)blockIdx.x * SC_TILE + 4 * (size_t)threadIdx.x;
@@ -166,8 +171,25 @@ k_scan_tiles(const TIn* in, TOut* out, size_t n, const TOut* __restrict__ sums) 
     incl[r] = wave_incl_scan<TOut>(mine[r], lane);
     if (lane == 63) lds[r * 4 + w] = incl[r];
   }
+  if constexpr (RAW_SUMS) {
+    TOut part = 0;
+    for (size_t i = threadIdx.x; i < blockIdx.x; i += SC_THREADS) part += sums[i];
+    part = wave_incl_scan<TOut>(part, lane);
+    if (lane == 63) lds_before[w] = part;
+  }
   __syncthreads();
-  TOut before = sums[blockIdx.x];  // everything ahead of (stripe r, wave w) in the tile's order
+  TOut before;  // everything ahead of (stripe r, wave w) in the tile's order
+  if constexpr (RAW_SUMS) {
+    before = lds_before[0] + lds_before[1] + lds_before[2] + lds_before[3];
+    if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+      TOut t = before;
+#pragma unroll
+      for (int k = 0; k < SC_STRIPES * 4; ++k) t += lds[k];
+      *total_out = t;
+    }
+  } else {
+    before = sums[blockIdx.x];
+  }
 #pragma unroll
   for (int r = 0; r < SC_STRIPES; ++r) {
     TOut here = before;
@@ -194,9 +216,14 @@ static void exclusive_scan(DevPool& pool, const TIn* in, TOut* out, size_t n, TO
   }
   const size_t nb = (n + SC_TILE - 1) / SC_TILE;
   DevBuf<TOut> sums(pool, nb);
-  hipLaunchKernelGGL((k_scan_tile_sums<TIn, TOut>), dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, n, sums.p);
-  hipLaunchKernelGGL((k_scan_sums<TOut>), dim3(1), dim3(SC_THREADS), 0, s, sums.p, nb, total);
-  hipLaunchKernelGGL((k_scan_tiles<TIn, TOut>), dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, out, n, sums.p);
+  if (nb <= SC_FUSED_TILES) {  // two launches (one for a single tile): the tiles add up the sums before them themselves
+    if (nb > 1) hipLaunchKernelGGL((k_scan_tile_sums<TIn, TOut>), dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, n, sums.p);
+    hipLaunchKernelGGL((k_scan_tiles<TIn, TOut, true>), dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, out, n, sums.p, total);
+  } else {
+    hipLaunchKernelGGL((k_scan_tile_sums<TIn, TOut>), dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, n, sums.p);
+    hipLaunchKernelGGL((k_scan_sums<TOut>), dim3(1), dim3(SC_THREADS), 0, s, sums.p, nb, total);
+    hipLaunchKernelGGL((k_scan_tiles<TIn, TOut, false>), dim3((unsigned)nb), dim3(SC_THREADS), 0, s, in, out, n, sums.p, (TOut*)nullptr);
+  }
   DX_HIP(hipGetLastError());
   // `sums` returns to the pool here; later launches on the same stream are ordered behind the
   // kernels above, so handing the block out again is safe as long as all work shares stream `s`.
