@@ -1347,44 +1347,6 @@ hipEvent_t pooled_event(dx_ctx* ctx, size_t i) {
   }
   return ctx->part_events[i];
 }
-// Counts and other small results come back through one pinned block. A copy into pinned memory is queued on the
-// stream like a kernel; a copy into pageable memory makes the host wait for each one on its own (20-40 us apiece,
-// with the GPU idle). add() queues, sync() waits for the stream and hands the values out; collect() hands out
-// after a synchronisation that has happened anyway. The block is handed out from its start again at every
-// partition call; what does not fit is copied the slow way.
-constexpr size_t kPartHostBytes = 256 << 10;
-struct HostFetch {
-  dx_ctx* ctx;
-  struct Item { void* dst; size_t off, bytes; };
-  std::vector<Item> items;
-  explicit HostFetch(dx_ctx* c) : ctx(c) {}
-  void add(void* dst, const void* dev, size_t bytes) {
-    if (!bytes) return;
-    if (!ctx->part_host) {
-      void* p = nullptr;
-      DX_HIP(hipHostMalloc(&p, kPartHostBytes, hipHostMallocDefault));
-      ctx->part_host = static_cast<uint8_t*>(p);
-      ctx->part_host_used = 0;
-    }
-    const size_t off = (ctx->part_host_used + 15) & ~(size_t)15;
-    if (off + bytes > kPartHostBytes) {
-      DX_HIP(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-      return;
-    }
-    DX_HIP(hipMemcpyAsync(ctx->part_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->part_host_used = off + bytes;
-    items.push_back({dst, off, bytes});
-  }
-  void collect() {
-    for (const Item& it : items) std::memcpy(it.dst, ctx->part_host + it.off, it.bytes);
-    items.clear();
-  }
-  void sync() {
-    DX_HIP(hipStreamSynchronize(ctx->stream));
-    collect();
-  }
-};
-
 // out[i] = in[i * stride]
 __global__ void k_pick_strided(const uint32_t* __restrict__ in, size_t stride, int n, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

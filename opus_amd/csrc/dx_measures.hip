@@ -228,6 +228,8 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   DevPool& pool = ctx->pool;
   MeasureState& ms = ctx->measures;
   ms = MeasureState();
+  HostFetch fetch(ctx);
+  const size_t fetch_mark = ctx->part_host_used;  // the pinned block is handed out from here again when this call is over
   // Several GPUs: the measures count every input triple once, wherever (and whether) it was placed, and a type
   // stated on two ranks counts twice. Every rank therefore gathers all ranks' own triples -- 8 bytes apiece, 11 GB
   // for the largest configuration, against 288 GB of HBM -- sorts them and computes the (schema-sized) result for
@@ -263,6 +265,7 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
     DX_HIP(hipEventSynchronize(e1));
     float msec = 0;
     DX_HIP(hipEventElapsedTime(&msec, e0, e1));
+    ctx->part_host_used = fetch_mark;
     ms.valid = true;
     if (out) {
       out->n_classes = ms.class_term.size();
@@ -281,8 +284,8 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   const uint64_t k1 = last_pred ? ~0ull : (uint64_t)(ps.type_pidx + 1) << (2 * bt);
   hipLaunchKernelGGL(k_ms_bounds, dim3(1), dim3(64), 0, s, keys, n, k0, k1, bounds.p);
   uint32_t hb[2] = {0, 0};
-  DX_HIP(hipMemcpyAsync(hb, bounds.p, 8, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(hb, bounds.p, 8);
+  fetch.sync();
   const uint32_t tb = hb[0], nt = (last_pred ? n : hb[1]) - hb[0];
   if (!nt) { finish(); return; }
   const uint64_t* tkeys = keys + tb;
@@ -291,8 +294,8 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   hipLaunchKernelGGL(k_ms_heads, dim3(blocks(nt)), dim3(256), 0, s, tkeys, nt, head.p);
   exclusive_scan_u8_u32(pool, head.p, pos.p, nt, d_tot.p, s);
   uint32_t n_ent = 0;
-  DX_HIP(hipMemcpyAsync(&n_ent, d_tot.p, 4, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(&n_ent, d_tot.p, 4);
+  fetch.sync();
   ms.n_type_entries = n_ent;
   DevBuf<uint32_t> ent_s(pool, n_ent), ent_c(pool, n_ent), ent_at(pool, (size_t)n_ent + 1);
   DevBuf<uint8_t> class_used(pool, n_terms);
@@ -303,8 +306,8 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   DX_HIP(hipMemcpyAsync(ent_at.p + n_ent, &nt, 4, hipMemcpyHostToDevice, s));
   exclusive_scan_u8_u32(pool, class_used.p, class_idx.p, n_terms, d_tot.p + 1, s);
   uint32_t n_classes = 0;
-  DX_HIP(hipMemcpyAsync(&n_classes, d_tot.p + 1, 4, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));  // also: nt has been read by the copy above
+  fetch.add(&n_classes, d_tot.p + 1, 4);
+  fetch.sync();  // also: nt has been read by the copy above
   head.reset(); pos.reset();
   DevBuf<uint32_t> class_term(pool, n_classes);
   DevBuf<uint8_t> class_ok(pool, n_classes);
@@ -329,13 +332,13 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   DevBuf<uint64_t> row_pos(pool, n), d_tot64(pool, 1);
   exclusive_scan_u32_u64(pool, cc_rows.p, row_pos.p, n, d_tot64.p, s);
   uint64_t R = 0;
-  DX_HIP(hipMemcpyAsync(&R, d_tot64.p, 8, hipMemcpyDeviceToHost, s));
+  fetch.add(&R, d_tot64.p, 8);
   std::vector<uint32_t> h_class(n_classes);
   std::vector<unsigned long long> h_freq(n_classes), h_count(n_classes);
-  DX_HIP(hipMemcpyAsync(h_class.data(), class_term.p, (size_t)n_classes * 4, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipMemcpyAsync(h_freq.data(), freq.p, (size_t)n_classes * 8, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipMemcpyAsync(h_count.data(), count.p, (size_t)n_classes * 8, hipMemcpyDeviceToHost, s));
-  DX_HIP(hipStreamSynchronize(s));
+  fetch.add(h_class.data(), class_term.p, (size_t)n_classes * 4);
+  fetch.add(h_freq.data(), freq.p, (size_t)n_classes * 8);
+  fetch.add(h_count.data(), count.p, (size_t)n_classes * 8);
+  fetch.sync();
   ms.class_term.assign(h_class.begin(), h_class.end());
   ms.node_freq.assign(h_freq.begin(), h_freq.end());
   ms.node_count.assign(h_count.begin(), h_count.end());
@@ -358,17 +361,17 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
     exclusive_scan_u8_u32(pool, head_i.p, dpos.p, r, dpos.p + r, s);
     exclusive_scan_u32_u64(pool, w.p, wpos.p, r, wpos.p + r, s);
     uint32_t G = 0;
-    DX_HIP(hipMemcpyAsync(&G, gpos.p + r, 4, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(&G, gpos.p + r, 4);
+    fetch.sync();
     DevBuf<uint64_t> g_key(pool, G), g_rows(pool, G), g_dist(pool, G);
     DevBuf<uint32_t> g_start(pool, G);
     hipLaunchKernelGGL(k_ms_cc_groups, dim3(blocks(r)), dim3(256), 0, s, key.p, head_g.p, gpos.p, r, bt, g_key.p, g_start.p);
     hipLaunchKernelGGL(k_ms_cc_finish, dim3(blocks(G)), dim3(256), 0, s, g_start.p, G, r, wpos.p, dpos.p, g_rows.p, g_dist.p);
     std::vector<uint64_t> hk(G), hr(G), hd(G);
-    DX_HIP(hipMemcpyAsync(hk.data(), g_key.p, (size_t)G * 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(hr.data(), g_rows.p, (size_t)G * 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipMemcpyAsync(hd.data(), g_dist.p, (size_t)G * 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+    fetch.add(hk.data(), g_key.p, (size_t)G * 8);
+    fetch.add(hr.data(), g_rows.p, (size_t)G * 8);
+    fetch.add(hd.data(), g_dist.p, (size_t)G * 8);
+    fetch.sync();
     const uint64_t cm = (1ull << bits_class) - 1, pm = (1ull << bits_pred) - 1;
     for (uint32_t g = 0; g < G; ++g) {
       ms.cc_obj.push_back((int64_t)h_class[hk[g] & cm]);
