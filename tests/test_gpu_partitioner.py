@@ -282,3 +282,23 @@ def test_control_characters_inside_and_around_fields(engine, seed):
     text = "\n".join(lines) + "\n"
     ci = "<C0>\t0\n<C1>\t1\n<C2>\t0,1\n"
     _run(engine, text, ci, 2)
+
+
+@pytest.mark.parametrize("boundary", [16, 1024, 8192, 32768, 65536])
+def test_line_ends_on_every_kind_of_boundary(engine, boundary):
+    """LF, CR LF and a lone CR placed just before, across and just after the edges the line scan works in (a lane's 16
+    bytes, a wave's 1 KiB step, a wave's 8 KiB stretch, a 32 KiB tile), each followed by a comment line or a triple
+    that starts exactly there."""
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    ci = "<A>\t0\n<B>\t1\n"
+    head = "<s0> " + T + " <A> .\n<s1> " + T + " <B> .\n<s0> <p> <s1> .\n"
+    for shift in (-2, -1, 0, 1):
+        for end in ("\n", "\r\n", "\r"):
+            for follower in ("# a comment\n<s2> <p> <s0> .\n", "<s3> <q> \"lit\" .\n# tail\n"):
+                # a triple with a long literal whose line terminator begins at byte boundary + shift
+                stem = head + "<s1> <name> \""
+                edge = -(-(len(stem) + 8) // boundary) * boundary   # the first such edge the stem leaves room for
+                fill = edge + shift - len(stem) - len("\" .")
+                text = stem + "x" * fill + "\" ." + end + follower + "<s1> <p> <s0> ." + end
+                assert text.index(end, len(stem)) == edge + shift
+                _run(engine, text, ci, 2)
