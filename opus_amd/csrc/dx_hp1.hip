@@ -1044,8 +1044,15 @@ __device__ __forceinline__ int partition_of_row(const uint32_t* __restrict__ par
 __global__ void __launch_bounds__(256)
 k_table_starts(const uint32_t* __restrict__ row_p, const uint32_t* __restrict__ part_base /*nparts+1*/, int nparts, uint32_t np,
                uint32_t* __restrict__ start) {
-  // four consecutive rows per lane (one 16-byte load), grid-stride: a block per 256 rows would spend its time being launched
+  // four consecutive rows per lane (one 16-byte load), grid-stride: a block per 256 rows would spend its time being launched.
+  // A table starts where the predicate changes or a partition begins. The second kind is written by the first lanes
+  // of block 0; the first kind is met a few hundred times among millions of rows, and only there is the row's
+  // partition looked up.
   const uint32_t total = part_base[nparts];
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)nparts) {
+    const uint32_t b = part_base[threadIdx.x];
+    if (b < part_base[threadIdx.x + 1]) start[(size_t)threadIdx.x * np + row_p[b]] = b;
+  }
   for (uint32_t i0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i0 < total; i0 += 4 * gridDim.x * blockDim.x) {
     uint32_t p[4];
     if (i0 + 4 <= total) {
@@ -1054,13 +1061,14 @@ k_table_starts(const uint32_t* __restrict__ row_p, const uint32_t* __restrict__ 
     } else {
       for (int k = 0; k < 4; ++k) p[k] = i0 + k < total ? row_p[i0 + k] : 0;
     }
-    uint32_t prev = i0 ? row_p[i0 - 1] : 0;
-    int q = 0;
-    while (q + 1 < nparts && i0 >= part_base[q + 1]) ++q;
+    uint32_t prev = i0 ? row_p[i0 - 1] : p[0];
     for (int k = 0; k < 4 && i0 + k < total; ++k) {
-      const uint32_t i = i0 + k;
-      while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
-      if (i == part_base[q] || prev != p[k]) start[(size_t)q * np + p[k]] = i;
+      if (prev != p[k]) {
+        const uint32_t i = i0 + k;
+        int q = 0;
+        while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+        start[(size_t)q * np + p[k]] = i;
+      }
       prev = p[k];
     }
   }
