@@ -741,24 +741,48 @@ k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ 
   if (valid) t_slot[i] = run_slot;
 }
 
-// first[i] = 1 when occurrence i is its slot's representative (the earliest occurrence of its term in the text)
+// first[i] = 1 when occurrence i is its slot's representative (the earliest occurrence of its term in the text).
+// Four occurrences per lane: 32- and 16-byte loads, the four slot reads in flight together, one 4-byte store.
 __global__ void __launch_bounds__(256)
 k_dict_first(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot, uint64_t n_occ, const DictSlot* __restrict__ ht,
              uint8_t* __restrict__ first) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_occ) first[i] = t_rep[i] == ht[t_slot[i]].val;
+  const uint64_t i0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i0 >= n_occ) return;
+  if (i0 + 4 <= n_occ) {
+    const ulonglong2 r01 = *reinterpret_cast<const ulonglong2*>(t_rep + i0), r23 = *reinterpret_cast<const ulonglong2*>(t_rep + i0 + 2);
+    const uint4 sl = *reinterpret_cast<const uint4*>(t_slot + i0);
+    const uint64_t v0 = ht[sl.x].val, v1 = ht[sl.y].val, v2 = ht[sl.z].val, v3 = ht[sl.w].val;
+    *reinterpret_cast<uint32_t*>(first + i0) = (uint32_t)(r01.x == v0) | ((uint32_t)(r01.y == v1) << 8) | ((uint32_t)(r23.x == v2) << 16) |
+                                              ((uint32_t)(r23.y == v3) << 24);
+  } else {
+    for (uint64_t i = i0; i < n_occ; ++i) first[i] = t_rep[i] == ht[t_slot[i]].val;
+  }
 }
 
+// One occurrence in twelve is a first one: a lane looks at four flags at once and does the work of those set.
+// (Sixteen per lane measured slower: too few lanes left to hide the dependent loads of the ones that have work.)
 __global__ void __launch_bounds__(256)
 k_dict_assign(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot, const uint8_t* __restrict__ first,
               const uint32_t* __restrict__ first_scan, uint64_t n_occ, DictSlot* __restrict__ ht,
               uint32_t* __restrict__ term_len, uint64_t* __restrict__ term_src) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_occ || !first[i]) return;
-  const uint32_t id = first_scan[i];
-  ht[t_slot[i]].val = id;  // the representative word has done its job: the slot now maps hash -> id
-  term_len[id] = (uint32_t)(t_rep[i] & ((1ull << kRepLenBits) - 1));
-  term_src[id] = t_rep[i] >> kRepLenBits;
+  const uint64_t i0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i0 >= n_occ) return;
+  uint32_t m = 0;
+  if (i0 + 4 <= n_occ) {
+    m = *reinterpret_cast<const uint32_t*>(first + i0);
+  } else {
+    for (uint64_t i = i0; i < n_occ; ++i) m |= (uint32_t)(first[i] != 0) << (8 * (i - i0));
+  }
+  while (m) {
+    const int bit = __ffs((int)m) - 1;  // flags are bytes holding 0 or 1
+    m &= m - 1;
+    const uint64_t i = i0 + (bit >> 3);
+    const uint32_t id = first_scan[i];
+    const uint64_t rep = t_rep[i];
+    ht[t_slot[i]].val = id;  // the representative word has done its job: the slot now maps hash -> id
+    term_len[id] = (uint32_t)(rep & ((1ull << kRepLenBits) - 1));
+    term_src[id] = rep >> kRepLenBits;
+  }
 }
 
 // Encoded records (s, p, o as term ids) + per-term facts that follow from the record kinds. Each fact has
@@ -1690,7 +1714,7 @@ void globalise_dictionary(dx_ctx* ctx, uint32_t n_rec, uint32_t* S, uint32_t* P,
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_global + 1) * 4, s));
   DevBuf<uint32_t> gid(pool, E);
   if (E) {
-    hipLaunchKernelGGL(k_dict_assign, dim3(blocks(E)), dim3(256), 0, s, e_rep.p, e_slot.p, first.p, first_scan.p, E, ht.p, term_len.p, term_src.p);
+    hipLaunchKernelGGL(k_dict_assign, dim3(blocks((E + 3) / 4)), dim3(256), 0, s, e_rep.p, e_slot.p, first.p, first_scan.p, E, ht.p, term_len.p, term_src.p);
     hipLaunchKernelGGL(k_entry_ids, dim3(blocks(E)), dim3(256), 0, s, e_slot.p, ht.p, E, gid.p);
   }
   Dictionary g;
@@ -1786,7 +1810,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
                          hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec,
                          ht.p, cap - 1, t_rep.p, t_slot.p, kind.p, err.p, coll.p);
     DX_HIP(hipEventRecord(e2, s));
-    if (n_occ) hipLaunchKernelGGL(k_dict_first, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, n_occ, ht.p, first.p);
+    if (n_occ) hipLaunchKernelGGL(k_dict_first, dim3(blocks((n_occ + 3) / 4)), dim3(256), 0, s, t_rep.p, t_slot.p, n_occ, ht.p, first.p);
     DX_HIP(hipEventRecord(e3, s));
     exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
     unsigned long long h_err = ~0ull;
@@ -1824,7 +1848,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemsetAsync(fact.p, 0, fact.bytes(), s));
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
-    hipLaunchKernelGGL(k_dict_assign, dim3(blocks(n_occ)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, ht.p,
+    hipLaunchKernelGGL(k_dict_assign, dim3(blocks((n_occ + 3) / 4)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, ht.p,
                        term_len.p, term_src.p);
     hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_slot.p, ht.p, kind.p, n_rec, S.p, P.p, O.p,
                        fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
