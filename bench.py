@@ -395,7 +395,7 @@ def main():
                                         "cc_groups": measures["n_cc"], "cc_rows": measures["n_cc_rows"]}
         if sharded is not None:
             out["sharded_queries"] = sharded
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # timed beside the single-GPU run only: the other ranks would wait for it
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
