@@ -681,8 +681,15 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
         }
         if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
         if (pa.nkey > 0) {
+          // Chained table: any number of heads is correct, fewer only means longer chains. Two heads per row
+          // that is expected (four times the planner's estimate, to be safe), never fewer than an eighth of the
+          // rows that could arrive: the heads of all steps are filled by k_query_init and read at random by the
+          // probes, so a table sized for the buffer's capacity costs time in both when the filters are selective.
+          uint64_t expect = I.cap;
+          if (k - 1 < (int)plan.est_rows.size())
+            expect = std::min<uint64_t>(I.cap, std::max<uint64_t>((uint64_t)std::min(4.0 * plan.est_rows[k - 1], 4.0e9), I.cap / 16));
           uint32_t hsize = 1024;
-          while (hsize < 2ull * I.cap && hsize < (1u << 31)) hsize <<= 1;
+          while (hsize < 2ull * expect && hsize < (1u << 31)) hsize <<= 1;
           my_heads_off = heads_words;
           heads_words += hsize;
           tmp32.emplace_back(pool, std::max<uint32_t>(I.cap, 1));
