@@ -1472,12 +1472,12 @@ void dict_lookup(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64
   DevBuf<uint8_t> q(ctx->pool, nbytes + 1);
   DevBuf<uint64_t> qo(ctx->pool, n + 1);
   DevBuf<int64_t> out(ctx->pool, n);
-  DX_HIP(hipMemcpyAsync(q.p, bytes, nbytes, hipMemcpyHostToDevice, s));
-  DX_HIP(hipMemcpyAsync(qo.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_lookup, dim3(blocks(n, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)n, d.seed, d.ht.p,
-                     d.ht_mask, d.pool.p, d.pool_off.p, out.p);
   HostFetch fetch(ctx);
   const size_t mark = ctx->part_host_used;
+  fetch.upload(q.p, bytes, nbytes);
+  fetch.upload(qo.p, offsets, (n + 1) * 8);
+  hipLaunchKernelGGL(k_lookup, dim3(blocks(n, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)n, d.seed, d.ht.p,
+                     d.ht_mask, d.pool.p, d.pool_off.p, out.p);
   fetch.add(ids_host, out.p, n * 8);
   fetch.sync();
   ctx->part_host_used = mark;  // nothing of this call is left in the block
@@ -1906,8 +1906,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DX_HIP(hipMemsetAsync(Pm.p, 0, Pm.bytes() ? Pm.bytes() : 8, s));
   DX_HIP(hipMemsetAsync(M.p, 0, M.bytes() ? M.bytes() : 8, s));
   int64_t type_term = -1;
-  std::vector<int64_t> class_ids;     // these two are copied to the device from where they lie: they stay until
-  std::vector<uint64_t> class_masks;  // the stream has been synchronised again (the predicate count below)
+  std::vector<int64_t> class_ids;     // both go to the device through the pinned block
+  std::vector<uint64_t> class_masks;
   {
     std::string bytes;
     std::vector<uint64_t> offs{0};
@@ -1922,8 +1922,8 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     if (!classes.empty() && n_terms) {
       DevBuf<int64_t> dids(pool, classes.size());
       DevBuf<uint64_t> dmask(pool, classes.size());
-      DX_HIP(hipMemcpyAsync(dids.p, ids.data(), classes.size() * 8, hipMemcpyHostToDevice, s));
-      DX_HIP(hipMemcpyAsync(dmask.p, masks.data(), classes.size() * 8, hipMemcpyHostToDevice, s));
+      fetch.upload(dids.p, ids.data(), classes.size() * 8);
+      fetch.upload(dmask.p, masks.data(), classes.size() * 8);
       hipLaunchKernelGGL(k_set_class_masks, dim3(blocks(classes.size())), dim3(256), 0, s, dids.p, dmask.p, (uint32_t)classes.size(), Pm.p);
     }
   }
@@ -1941,40 +1941,48 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   // ---- 6. predicates, sort keys
   DevBuf<uint32_t> pred_index(pool, (size_t)n_terms + 1);
   exclusive_scan_u8_u32(pool, is_pred, pred_index.p, n_terms, d_total.p, s);
+  // The list of predicates is written before the host knows how many there are (room for every term), and the
+  // first kPredsAtOnce of them come back with the count: one wait instead of two for any ordinary schema.
+  constexpr uint32_t kPredsAtOnce = 1024;
+  DevBuf<uint32_t> d_preds(pool, (size_t)n_terms + 1);
   uint32_t np = 0;
-  fetch.add(&np, d_total.p, 4);
-  fetch.sync();
-  st.n_predicates = np;
   {
-    DevBuf<uint32_t> d_preds(pool, np ? np : 1);
     DevBuf<unsigned long long> d_nv(pool, 1);
     DX_HIP(hipMemsetAsync(d_nv.p, 0, 8, s));
     if (n_terms)
       hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 256u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
-    std::vector<uint32_t> hp(np);
+    const uint32_t at_once = (uint32_t)std::min<uint64_t>(kPredsAtOnce, n_terms);
+    std::vector<uint32_t> hp(at_once);
     unsigned long long nv = 0;
-    fetch.add(hp.data(), d_preds.p, (size_t)np * 4);
+    fetch.add(&np, d_total.p, 4);
+    fetch.add(hp.data(), d_preds.p, (size_t)at_once * 4);
     fetch.add(&nv, d_nv.p, 8);
     fetch.sync();
+    if (np > at_once) {
+      hp.resize(np);
+      fetch.add(hp.data() + at_once, d_preds.p + at_once, (size_t)(np - at_once) * 4);
+      fetch.sync();
+    }
+    hp.resize(np);
+    st.n_predicates = np;
     ps.pred_terms.assign(hp.begin(), hp.end());
     st.n_vertices = nv;
   }
   // The predicates' strings are wanted by the host at the very end. Their lengths are gathered now and their bytes
   // packed after the split, so that both come back with synchronisations that happen anyway (a schema with ten
   // thousand predicates would otherwise queue twenty thousand small copies, or wait twice more).
-  const std::vector<uint32_t> pred_ids32(ps.pred_terms.begin(), ps.pred_terms.end());
   std::vector<uint64_t> pred_off((size_t)np + 1, 0);
   std::string pred_bytes;
   DevBuf<uint64_t> d_pred_src(pool, np), d_pred_off(pool, (size_t)np + 1);
   if (np) {
-    DevBuf<uint32_t> d_ids(pool, np), d_len(pool, (size_t)np + 1);
+    DevBuf<uint32_t> d_len(pool, (size_t)np + 1);
     DevBuf<uint64_t> d_tot(pool, 1);
-    DX_HIP(hipMemcpyAsync(d_ids.p, pred_ids32.data(), (size_t)np * 4, hipMemcpyHostToDevice, s));
     DX_HIP(hipMemsetAsync(d_len.p + np, 0, 4, s));
-    hipLaunchKernelGGL(k_term_spans, dim3(blocks(np)), dim3(256), 0, s, d_ids.p, np, d.pool_off.p, d_pred_src.p, d_len.p);
+    hipLaunchKernelGGL(k_term_spans, dim3(blocks(np)), dim3(256), 0, s, d_preds.p, np, d.pool_off.p, d_pred_src.p, d_len.p);
     exclusive_scan_u32_u64(pool, d_len.p, d_pred_off.p, (size_t)np + 1, d_tot.p, s);
     fetch.add(pred_off.data(), d_pred_off.p, ((size_t)np + 1) * 8);
   }
+  d_preds.reset();
   const int bits_term = bits_for(n_terms ? n_terms : 1), bits_pred = bits_for(np ? np : 1);
   if (bits_pred + 2 * bits_term > 64 || bits_for(nparts) + bits_term + 1 + bits_pred > 64)
     throw DxError(DX_E_RANGE, "dictionary too large for 64-bit packed sort keys on one GPU");

@@ -164,6 +164,26 @@ struct HostFetch {
     ctx->part_host_used = off + bytes;
     items.push_back({dst, off, bytes});
   }
+  // Host to device through the same pinned block: the bytes are copied into it now (the caller's memory is free
+  // again at once) and travel with the stream; a copy from pageable memory is staged by the runtime call by call.
+  void upload(void* dev, const void* src, size_t bytes) {
+    if (!bytes) return;
+    if (!ctx->part_host) {
+      void* p = nullptr;
+      DX_HIP(hipHostMalloc(&p, kPartHostBytes, hipHostMallocDefault));
+      ctx->part_host = static_cast<uint8_t*>(p);
+      ctx->part_host_used = 0;
+    }
+    const size_t off = (ctx->part_host_used + 15) & ~(size_t)15;
+    if (off + bytes > kPartHostBytes) {
+      DX_HIP(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+      DX_HIP(hipStreamSynchronize(ctx->stream));  // src may go away when the caller returns
+      return;
+    }
+    std::memcpy(ctx->part_host + off, src, bytes);
+    DX_HIP(hipMemcpyAsync(dev, ctx->part_host + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->part_host_used = off + bytes;
+  }
   void collect() {
     for (const Item& it : items) std::memcpy(it.dst, ctx->part_host + it.off, it.bytes);
     items.clear();
