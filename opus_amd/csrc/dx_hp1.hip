@@ -1905,24 +1905,27 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   DevBuf<uint64_t> Pm(pool, n_terms), M(pool, n_terms);
   DX_HIP(hipMemsetAsync(Pm.p, 0, Pm.bytes() ? Pm.bytes() : 8, s));
   DX_HIP(hipMemsetAsync(M.p, 0, M.bytes() ? M.bytes() : 8, s));
+  // The class URIs and rdf:type are looked up on the device and the ids stay there (the mask kernel reads them);
+  // the host only wants rdf:type's id, which comes back with the predicate count's wait below.
   int64_t type_term = -1;
-  std::vector<int64_t> class_ids;     // both go to the device through the pinned block
-  std::vector<uint64_t> class_masks;
   {
     std::string bytes;
     std::vector<uint64_t> offs{0};
-    std::vector<uint64_t>& masks = class_masks;
+    std::vector<uint64_t> masks;
     for (auto& c : classes) { bytes += c.uri; offs.push_back(bytes.size()); masks.push_back(c.mask); }
     bytes += "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>";
     offs.push_back(bytes.size());
-    std::vector<int64_t>& ids = class_ids;
-    ids.resize(offs.size() - 1);
-    dict_lookup(ctx, bytes.data(), offs.data(), ids.size(), ids.data());
-    type_term = ids.back();
+    const size_t nq = offs.size() - 1;
+    DevBuf<uint8_t> q(pool, bytes.size() + 1);
+    DevBuf<uint64_t> qo(pool, nq + 1);
+    DevBuf<int64_t> dids(pool, nq);
+    fetch.upload(q.p, bytes.data(), bytes.size());
+    fetch.upload(qo.p, offs.data(), (nq + 1) * 8);
+    hipLaunchKernelGGL(k_lookup, dim3(blocks(nq, 64)), dim3(64), 0, s, q.p, qo.p, (uint32_t)nq, d.seed, d.ht.p, d.ht_mask, d.pool.p,
+                       d.pool_off.p, dids.p);
+    fetch.add(&type_term, dids.p + (nq - 1), 8);
     if (!classes.empty() && n_terms) {
-      DevBuf<int64_t> dids(pool, classes.size());
       DevBuf<uint64_t> dmask(pool, classes.size());
-      fetch.upload(dids.p, ids.data(), classes.size() * 8);
       fetch.upload(dmask.p, masks.data(), classes.size() * 8);
       hipLaunchKernelGGL(k_set_class_masks, dim3(blocks(classes.size())), dim3(256), 0, s, dids.p, dmask.p, (uint32_t)classes.size(), Pm.p);
     }
