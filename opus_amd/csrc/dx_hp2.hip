@@ -148,8 +148,8 @@ k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* _
   if (!a.direct && ((a.fo >= 0) != (a.fs >= 0))) {
     const int64_t* __restrict__ col = a.fo >= 0 ? a.o : a.s;
     const int64_t want = consts[a.fo >= 0 ? a.fo : a.fs];
-    uint32_t i = t;
-    for (; (uint64_t)i + 7ull * nthreads < a.rows; i += 8 * nthreads) {
+    uint64_t i = t;  // 64-bit: the stride must not wrap on a table of nearly 2^32 rows
+    for (; i + 7ull * nthreads < a.rows; i += 8ull * nthreads) {
       int64_t v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = col[i + j * nthreads];
@@ -158,9 +158,9 @@ k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* _
     }
     for (; i < a.rows; i += nthreads) c += col[i] == want ? 1u : 0u;
   } else {
-    for (uint32_t i = t; i < a.rows; i += nthreads) {
+    for (uint64_t i = t; i < a.rows; i += nthreads) {
       int64_t v[3];
-      c += arm_row(a, consts, i, v) ? 1u : 0u;
+      c += arm_row(a, consts, (uint32_t)i, v) ? 1u : 0u;
     }
   }
   __shared__ uint32_t lds[8];
