@@ -147,14 +147,30 @@ def _p(a, t=c_int64):
 
 
 class QueryResult:
+    # count is read at once (it is what the reference's timed `result.count` returns); the other attributes are
+    # fetched from the handle when first asked for, or when the handle is closed, whichever comes first
+    _LAZY = ("local_rows", "columns", "device_ms", "plan")
+
     def __init__(self, engine, handle):
         self._e, self._h = engine, handle
-        lib = engine.lib
-        self.count = int(lib.dx_result_count(handle))            # over all ranks
-        self.local_rows = int(lib.dx_result_local_rows(handle))  # held by this rank (== count on one GPU)
-        self.columns = [lib.dx_result_column_name(handle, i).decode() for i in range(lib.dx_result_columns(handle))]
-        self.device_ms = float(lib.dx_result_device_ms(handle))
-        self.plan = lib.dx_result_plan(handle).decode()
+        self.count = int(engine.lib.dx_result_count(handle))     # over all ranks
+
+    def __getattr__(self, name):
+        if name not in QueryResult._LAZY:
+            raise AttributeError(name)
+        lib, handle = self._e.lib, self._h
+        if not handle:
+            raise AttributeError(name + " was not read before the result was closed")
+        if name == "local_rows":                                 # held by this rank (== count on one GPU)
+            v = int(lib.dx_result_local_rows(handle))
+        elif name == "columns":
+            v = [lib.dx_result_column_name(handle, i).decode() for i in range(lib.dx_result_columns(handle))]
+        elif name == "device_ms":
+            v = float(lib.dx_result_device_ms(handle))
+        else:
+            v = lib.dx_result_plan(handle).decode()
+        self.__dict__[name] = v
+        return v
 
     def ids(self, sort=False):
         """(count, n_columns) int64 array of term ids (needs DX_QUERY_BINDINGS)."""
@@ -183,6 +199,8 @@ class QueryResult:
 
     def close(self):
         if self._h:
+            for name in QueryResult._LAZY:   # what the handle knows stays readable after it is gone
+                getattr(self, name)
             self._e.lib.dx_result_free(self._h)
             self._h = None
 
