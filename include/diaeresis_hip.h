@@ -178,6 +178,16 @@ int dx_unload_all(dx_ctx* ctx);
 /* Replaces executeFinalQuery -> spark.sqlContext.sql(query) (QueryProcessor.scala:184-195) followed by
  * result.count. sql is one statement of the translated-query grammar (QueryTranslator.scala:363-392, 417-543). */
 int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out);
+/* No counterpart in the reference. The count of dx_query(sql, DX_QUERY_COUNT) for callers that cannot allocate
+ * device memory while they run: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc. The statement's device scratch (resolved constants, row counters, intermediate relations, hash-join
+ * heads and chains) comes out of one fixed 32 MiB array that every GPU the library runs on holds from load time
+ * until the process ends; the call makes no hipMalloc / hipFree. A statement that needs more returns DX_E_RANGE
+ * (use dx_query). The tables must have been loaded with dx_load_table / dx_load_tables (their statistics are
+ * gathered there; DX_E_INVAL otherwise); a UNION over a directory shared by several predicates must have gone
+ * through dx_query once. One GPU only (DX_E_UNSUPPORTED with a communicator set). All contexts of a GPU share
+ * the array: calls that overlap in time on one GPU race, so serialise them. */
+int dx_query_count_noalloc(dx_ctx* ctx, const char* sql, uint64_t* count);
 uint64_t dx_result_count(dx_result* r);
 int dx_result_columns(dx_result* r);
 const char* dx_result_column_name(dx_result* r, int i);

@@ -165,6 +165,13 @@ dx_ctx* dx_init(int device) {
     delete ctx;
     return nullptr;
   }
+  try {  // what the query path would otherwise create on first use; dx_query_count_noalloc must find it ready
+    query_context_setup(ctx);
+    ctx->noalloc_scratch = noalloc_scratch_of_current_device(&ctx->noalloc_scratch_bytes);
+  } catch (const std::exception&) {
+    dx_free(ctx);
+    return nullptr;
+  }
   return ctx;
 }
 
@@ -878,6 +885,14 @@ int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out) {
     if (!sql || !out) throw DxError(DX_E_INVAL, "null argument");
     if (mode != DX_QUERY_COUNT && mode != DX_QUERY_BINDINGS) throw DxError(DX_E_INVAL, "unknown query mode");
     *out = ctx->comm.world > 1 ? run_query_sharded(ctx, sql, mode) : run_query(ctx, sql, mode);
+  });
+}
+
+int dx_query_count_noalloc(dx_ctx* ctx, const char* sql, uint64_t* count) {
+  return guard(ctx, [&] {
+    if (!sql || !count) throw DxError(DX_E_INVAL, "null argument");
+    if (ctx->comm.world > 1) throw DxError(DX_E_UNSUPPORTED, "dx_query_count_noalloc runs on one GPU: the exchange between ranks allocates");
+    *count = run_query_count_noalloc(ctx, sql);
   });
 }
 

@@ -349,7 +349,10 @@ struct Plan {
 
 int find_root(std::vector<int>& uf, int x) { while (uf[x] != x) x = uf[x] = uf[uf[x]]; return x; }
 
-Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
+// may_allocate == false (the entry point that allocates nothing): whatever the plan needs beyond the tables
+// themselves -- their distinct counts, the duplicate-free copy of a table read by UNION arms -- has to exist
+// already, because gathering it takes device memory from the allocator.
+Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true) {
   Plan plan;
   const long long kLookup = (-0x7FFFFFFFFFFFFFFFll - 1);
   auto add_const = [&](const std::string& s, bool is_virtual) -> int {
@@ -413,9 +416,15 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
         auto it = ctx->catalog.find(arm.table);
         if (it == ctx->catalog.end()) continue;
         CatalogTable* t = &it->second;
-        if (sub.arms.size() > 1) t = const_cast<CatalogTable*>(distinct_view_of(ctx, *t));  // the view is owned by its table
+        if (sub.arms.size() > 1) {
+          if (!may_allocate && t->several_sources && t->rows >= 2 && !t->distinct_view)
+            throw DxError(DX_E_INVAL, "table " + t->view + " has no duplicate-free copy yet: run the statement through dx_query once");
+          t = const_cast<CatalogTable*>(distinct_view_of(ctx, *t));  // the view is owned by its table
+        }
         if (t->stats_pending) need.push_back(t);
       }
+    if (!may_allocate && !need.empty())
+      throw DxError(DX_E_INVAL, "table " + need[0]->view + " has no statistics yet: load it with dx_load_table or dx_load_tables");
     table_statistics(ctx, need);
   }
   // relations
@@ -441,6 +450,8 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q) {
       if (it == ctx->catalog.end()) throw DxError(DX_E_NOENT, "SQL: table or view not found: " + arm.table);
       PlanRel::Arm a;
       // a UNION is a set union: rows a shared directory holds twice come out once (a plain sub-select keeps them)
+      if (sub.arms.size() > 1 && !may_allocate && it->second.several_sources && it->second.rows >= 2 && !it->second.distinct_view)
+        throw DxError(DX_E_INVAL, "table " + it->second.view + " has no duplicate-free copy yet: run the statement through dx_query once");
       a.t = sub.arms.size() > 1 ? distinct_view_of(ctx, it->second) : &it->second;
       if (arm.has_s) a.fs = add_const(arm.s_const, false);
       if (arm.has_o) a.fo = add_const(arm.o_const, false);
@@ -565,17 +576,25 @@ struct QueryHostBlock {
   unsigned long long counters[MAXSTEPS + 2];
 };
 
-dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
+// The pinned block and the two events a statement uses, made once per context (dx_init): no statement creates
+// anything, so the entry point that allocates nothing can share this code.
+void query_context_setup(dx_ctx* ctx) {
+  if (!ctx->q_host) DX_HIP(hipHostMalloc(&ctx->q_host, sizeof(QueryHostBlock), hipHostMallocDefault));
+  if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }
+}
+
+// `pool` supplies every device buffer of the statement's execution: the context's caching allocator, or a
+// fixed arena (then may_allocate is false and nothing else may be allocated either).
+static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, DevPool& pool, bool may_allocate) {
   const auto t_host0 = std::chrono::steady_clock::now();
   const SqlQuery q = parse_sql(sql);
-  Plan plan = make_plan(ctx, q);
+  Plan plan = make_plan(ctx, q, may_allocate);
   const double plan_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
   if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
   for (auto& r : plan.rels)
     for (auto& a : r.arms)
       if (a.t->rows >= (1ull << 32)) throw DxError(DX_E_RANGE, "table with 2^32 rows or more");
   hipStream_t s = ctx->stream;
-  DevPool& pool = ctx->pool;
   const int nsteps = (int)plan.rels.size();
 
   ConstArgs ca;
@@ -591,11 +610,10 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
   }
   ca.off[ca.n] = off;
 
-  if (!ctx->q_host) DX_HIP(hipHostMalloc(&ctx->q_host, sizeof(QueryHostBlock), hipHostMallocDefault));
+  if (!ctx->q_host || !ctx->q_ev0) throw DxError(DX_E_INVAL, "context was not set up for queries");
   QueryHostBlock* hb = static_cast<QueryHostBlock*>(ctx->q_host);
 
   std::vector<uint64_t> caps(nsteps, 0);
-  if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }
   hipEvent_t ev0 = ctx->q_ev0, ev1 = ctx->q_ev1;
   auto* res = new dx_result();
   res->ctx = ctx;
@@ -603,6 +621,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
   res->virtual_terms = plan.virtual_terms;
   try {
     for (int attempt = 0; attempt <= nsteps + 1; ++attempt) {
+      if (pool.is_arena()) pool.rewind();  // a re-run with larger buffers starts from the arena's base again
       DevBuf<int64_t> consts(pool, kMaxConsts);
       DevBuf<unsigned long long> counters(pool, MAXSTEPS + 2);
       std::vector<std::vector<DevBuf<int64_t>>> step_cols(nsteps);
@@ -784,7 +803,7 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
           for (size_t j = 0; j < I_cls.size(); ++j)
             if (I_cls[j] == plan.select_cls[c]) at = (int)j;
           if (at < 0) throw DxError(DX_E_MALFORMED, "SQL: selected column is not produced by any sub-select");
-          DevBuf<int64_t> col(pool, res->count);
+          DevBuf<int64_t> col(ctx->pool, res->count);  // outlives the statement's buffers: never from an arena
           if (res->count) DX_HIP(hipMemcpyAsync(col.p, I.col[at], res->count * 8, hipMemcpyDeviceToDevice, s));
           res->cols.push_back(std::move(col));
         }
@@ -798,6 +817,37 @@ dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) {
     delete res;
     throw;
   }
+}
+
+dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode) { return run_query_in(ctx, sql, mode, ctx->pool, true); }
+
+// ---- a count that allocates nothing -----------------------------------------------------------------------
+// Everything a counting statement needs on the device beyond the tables themselves -- resolved constants, row
+// counters, the intermediate relations' columns, the hash-join heads and chains -- is carved out of one
+// file-scope device array instead of the caching allocator, for callers that cannot call hipMalloc (HIP graph
+// capture, tight serving loops). Each GPU the library runs on holds its own copy of the array at its own
+// address until the process ends; all contexts of a GPU share it, and it keeps the last call's contents (the
+// statement's first kernel resets the counters and the heads it will use).
+constexpr size_t kNoAllocScratchBytes = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+// With `device` current: the address of that GPU's copy of the array. In host code the array's name is only a
+// handle for this call; kernels, memsets and copies take the pointer returned here.
+void* noalloc_scratch_of_current_device(size_t* bytes) {
+  void* ptr = nullptr;
+  DX_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) throw DxError(DX_E_HIP, "hipGetSymbolAddress returned no address for the scratch array");
+  *bytes = kNoAllocScratchBytes;
+  return ptr;
+}
+
+uint64_t run_query_count_noalloc(dx_ctx* ctx, const std::string& sql) {
+  if (!ctx->noalloc_scratch) throw DxError(DX_E_INVAL, "context has no scratch array");
+  DevPool arena(ctx->noalloc_scratch, ctx->noalloc_scratch_bytes);
+  dx_result* r = run_query_in(ctx, sql, DX_QUERY_COUNT, arena, false);
+  const uint64_t n = r->count;
+  delete r;
+  return n;
 }
 
 

@@ -36,7 +36,15 @@ struct DxError : std::runtime_error {
 // repeated, so freed blocks are kept and handed out again instead of going back to hipMalloc.
 class DevPool {
  public:
+  DevPool() = default;
+  // Fixed arena: hands out pieces of [base, base + bytes) one after another and never calls the HIP allocator;
+  // a request that does not fit throws DX_E_RANGE. release() is a no-op, rewind() starts from the base again.
+  DevPool(void* base, size_t bytes) : arena_base_(static_cast<uint8_t*>(base)), arena_bytes_(bytes) {}
+  DevPool(const DevPool&) = delete;
+  DevPool& operator=(const DevPool&) = delete;
   ~DevPool() { trim(); }
+  bool is_arena() const { return arena_base_ != nullptr; }
+  void rewind() { arena_used_ = 0; }
   void* alloc(size_t bytes);
   void release(void* p);   // back to the cache
   void trim();             // hipFree everything cached (live blocks stay live)
@@ -46,6 +54,8 @@ class DevPool {
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> live_;
   size_t live_bytes_ = 0;
+  uint8_t* arena_base_ = nullptr;
+  size_t arena_bytes_ = 0, arena_used_ = 0;
 };
 
 template <typename T>

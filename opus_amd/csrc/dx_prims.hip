@@ -12,6 +12,15 @@ static size_t round_alloc(size_t b) {
   return (b + g - 1) / g * g;
 }
 void* DevPool::alloc(size_t bytes) {
+  if (arena_base_) {
+    const size_t sz = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    if (sz > arena_bytes_ - arena_used_)
+      throw DxError(DX_E_RANGE, "the statement needs more device scratch than the fixed " + std::to_string(arena_bytes_ >> 20) +
+                                    " MiB of the entry point that allocates nothing");
+    void* p = arena_base_ + arena_used_;
+    arena_used_ += sz;
+    return p;
+  }
   const size_t sz = round_alloc(bytes ? bytes : 1);
   auto it = free_.find(sz);
   void* p = nullptr;
@@ -31,6 +40,7 @@ void* DevPool::alloc(size_t bytes) {
   return p;
 }
 void DevPool::release(void* p) {
+  if (arena_base_) return;
   auto it = live_.find(p);
   if (it == live_.end()) return;
   free_.emplace(it->second, p);
@@ -38,6 +48,7 @@ void DevPool::release(void* p) {
   live_.erase(it);
 }
 void DevPool::trim() {
+  if (arena_base_) return;
   for (auto& kv : free_) (void)hipFree(kv.second);
   free_.clear();
 }

@@ -131,6 +131,9 @@ struct dx_ctx {
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
   uint8_t* part_host = nullptr;         // pinned block the partitioner's small results come back through
   size_t part_host_used = 0;
+  // this GPU's copy of the file-scope scratch array behind dx_query_count_noalloc (address looked up in dx_init)
+  void* noalloc_scratch = nullptr;
+  size_t noalloc_scratch_bytes = 0;
   // several GPUs: collectives handed in by the host; world == 1 means single-GPU execution
   dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -221,6 +224,9 @@ const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t);
 void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
+void query_context_setup(dx_ctx* ctx);                      // pinned block + events of the query path, once per context
+void* noalloc_scratch_of_current_device(size_t* bytes);     // the device array behind dx_query_count_noalloc
+uint64_t run_query_count_noalloc(dx_ctx* ctx, const std::string& sql);
 dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode);
 extern const char* const kStageNames[12];
 }  // namespace dx

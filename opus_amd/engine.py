@@ -33,6 +33,7 @@ EXPORTS = [
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
     "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
+    "dx_query_count_noalloc",
 ]
 
 
@@ -114,6 +115,7 @@ def load_library():
         "dx_load_tables": (c_int, [c_void_p, POINTER(c_char_p), c_int, u64p]),
         "dx_unload_all": (c_int, [c_void_p]),
         "dx_query": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_void_p)]),
+        "dx_query_count_noalloc": (c_int, [c_void_p, c_char_p, u64p]),
         "dx_result_count": (c_uint64, [c_void_p]),
         "dx_result_columns": (c_int, [c_void_p]),
         "dx_result_column_name": (c_char_p, [c_void_p, c_int]),
@@ -403,6 +405,12 @@ class Engine:
     def set_table_stats(self, key: str, stats):
         arr = (c_uint64 * 3)(int(stats[0]), int(stats[1]), int(stats[2]))
         self._check(self.lib.dx_set_table_stats(self.ctx, key.encode(), arr))
+
+    def query_count_noalloc(self, sql: str) -> int:
+        """The count of query(sql), computed without any device allocation (fixed scratch array; one GPU)."""
+        n = c_uint64(0)
+        self._check(self.lib.dx_query_count_noalloc(self.ctx, sql.encode("utf-8", "surrogateescape"), byref(n)))
+        return n.value
 
     def query(self, sql: str, mode: int = DX_QUERY_COUNT) -> QueryResult:
         h = c_void_p(None)
