@@ -9,7 +9,10 @@ One step = one pass of both hot paths over one synthetic LUBM batch per GPU:
 
 Prints ONE JSON line (rank 0). `value` is partitioning throughput in triples/s over all ranks;
 the query geo-mean in ms is carried next to it. With --gpus N > 1 (launched by torchrun, one rank
-per GPU) every rank works on its own block of universities with no cross-rank exchange.
+per GPU) the ranks work on ONE data set together: every rank tokenises its block of universities, the
+ranks agree on one dictionary, route the triples to the owners of their first-level partitions
+(partition q lives on rank q % N) and answer the 13 queries together, with the join inputs exchanged by
+join key -- all over the communicator the library makes on RCCL (dx_comm_rccl_init).
 """
 from __future__ import annotations
 
@@ -135,6 +138,95 @@ def cpu_baseline():
                           "sample": "the same port on %d blocks of LUBM-10 side by side, one per thread" % threads}}
 
 
+def join_group(eng, args, rank, world, device):
+    """Puts this rank's context into the group of all ranks. Default: the communicator the library makes itself on
+    librccl (rank 0's unique id travels over torch.distributed, which the launcher has set up anyway). Every rank
+    first proves that it can load RCCL, so that no rank waits in ncclCommInitRank for one that never comes; if any
+    cannot, or with --comm torch / a gloo rehearsal, all ranks use torch.distributed through callbacks instead."""
+    import torch
+    import torch.distributed as dist
+    from opus_amd.engine import DxError, Engine
+    from opus_amd.host.comm import TorchComm
+    red = device if args.backend == "nccl" else torch.device("cpu")
+    kind = "torch.distributed callbacks (%s)" % args.backend
+    if args.comm == "rccl" and args.backend == "nccl" and not args.single_device:
+        try:
+            uid = Engine.rccl_unique_id()
+            ok = 1
+        except (DxError, OSError) as ex:
+            print("rank %d: cannot load RCCL natively (%s)" % (rank, ex), file=sys.stderr)
+            uid, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int64, device=red)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            box = [uid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            eng.comm_rccl_init(box[0], rank, world)
+            eng.comm_selftest()
+            return None, "library-native RCCL (ncclSend/ncclRecv groups on the context's stream)"
+    comm = TorchComm()
+    eng.set_comm(comm)
+    eng.comm_selftest()
+    return comm, kind
+
+
+def crosscheck_against_one_gpu(args, rank, world, local_rank, device, ontology, ci):
+    """The sharded paths against one GPU on a data set small enough for rank 0 to hold alone (LUBM-8): all ranks
+    partition it together and answer the 13 queries together, rank 0 then does the same alone on a second context,
+    and the counts must agree. Returns (universities, counts) on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_COUNT, Engine
+    n_univ = max(8, world)
+    e = Engine(local_rank)
+    try:
+        join_group(e, args, rank, world, device)
+        arr, _ = lubm.generate(rank * n_univ // world, (rank + 1) * n_univ // world, seed=0, ontology=ontology, degree_pool=3)
+        t = torch.from_numpy(arr).to(device)
+        torch.cuda.synchronize()
+        e.partition_device(t.data_ptr(), int(arr.size), ci, args.partitions)
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        queries = translated_queries(e, ci, ontology, gather=gather)
+        names = sorted(queries, key=lambda n: int(n[1:-4]))
+        together = {}
+        for n in names:
+            sql, parts = parse_translated(queries[n])
+            e.unload_all()
+            e.load_tables_sharded(parts)
+            r = e.query(sql, DX_QUERY_COUNT)
+            together[n] = int(r.count)
+            r.close()
+    finally:
+        e.close()
+    if rank != 0:
+        return None
+    whole, _ = lubm.generate(0, n_univ, seed=0, ontology=ontology, degree_pool=3)
+    e1 = Engine(local_rank)
+    try:
+        t = torch.from_numpy(whole).to(device)
+        torch.cuda.synchronize()
+        e1.partition_device(t.data_ptr(), int(whole.size), ci, args.partitions)
+        alone = {}
+        for n in names:
+            sql, parts = parse_translated(queries[n])
+            e1.unload_all()
+            e1.load_tables(list(dict.fromkeys(parts)))
+            r = e1.query(sql, DX_QUERY_COUNT)
+            alone[n] = int(r.count)
+            r.close()
+    finally:
+        e1.close()
+    if alone != together:
+        raise RuntimeError("sharded query counts differ from one GPU's on LUBM-%d: %r vs %r" % (n_univ, together, alone))
+    if not any(alone.values()):
+        raise RuntimeError("cross-check data set answers every query with 0 rows")
+    return n_univ, alone
+
+
 def sharded_query_leg(args, eng0, plans, qnames, want_counts, rank, world, local_rank, barrier):
     """Rank 0 writes its partitions as the reference lays them out; every rank opens that layout (one
     dictionary), loads the tables of the first-level partitions it owns, and all ranks answer the 13 queries
@@ -200,15 +292,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--universities", type=int, default=100, help="universities per GPU (100 = LUBM-100, ~14 M triples)")
+    ap.add_argument("--universities", type=int, default=0,
+                    help="universities in total (default: 100 = LUBM-100 on one GPU; 1300 * N / 8 on N > 1 GPUs, so that 8 GPUs "
+                         "hold LUBM-1300)")
     ap.add_argument("--partitions", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-queries", action="store_true",
                     help="extra leg for --gpus N > 1: rank 0's partitions are split over the ranks by first-level "
                          "partition and the 13 queries run on all GPUs together (hash exchange before every join)")
-    ap.add_argument("--global-partition", action="store_true",
-                    help="--gpus N > 1: the ranks partition the union of their blocks together (one dictionary, partitions "
-                         "owned by rank, triples exchanged) and answer the queries together, instead of working side by side")
+    ap.add_argument("--replicas", action="store_true",
+                    help="--gpus N > 1: independent replicas instead (every rank partitions and queries its own block, no exchange)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="communicator of the sharded run: the library's own over librccl, or torch.distributed through callbacks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
@@ -238,7 +333,8 @@ def main():
 
     # ---- synthetic input, resident in HBM before anything is timed
     ontology = 0
-    u0, u1 = shard.university_block(rank, world, args.universities)
+    total_univ = args.universities or (100 if world == 1 else max(world, round(1300 * world / 8)))
+    u0, u1 = rank * total_univ // world, (rank + 1) * total_univ // world
     arr, n_triples = lubm.generate(u0, u1, seed=0, ontology=ontology, degree_pool=1000)
     text = torch.from_numpy(arr).to("cuda:%d" % local_rank)
     n_bytes = int(arr.size)
@@ -246,12 +342,12 @@ def main():
     ci = lubm.class_index_text(args.partitions, ontology)
     torch.cuda.synchronize()
     eng = Engine(local_rank)
-    together = args.global_partition and world > 1
-    comm = None
+    together = world > 1 and not args.replicas
+    comm, comm_kind = None, "none"
+    crosscheck = None
     if together:
-        from opus_amd.host.comm import TorchComm, load_tables_sharded
-        comm = TorchComm()
-        eng.set_comm(comm)
+        comm, comm_kind = join_group(eng, args, rank, world, device)
+        crosscheck = crosscheck_against_one_gpu(args, rank, world, local_rank, device, ontology, ci)
 
     def gather_objects(obj):
         box = [None] * world
@@ -273,8 +369,8 @@ def main():
         for n in qnames:
             sql, parts = plans[n]
             eng.unload_all()                       # unloadTables of the previous query
-            if together:                           # tables stay with the rank that owns their partition
-                load_tables_sharded(eng, comm, parts, lambda q: shard.partition_owner(q, world))
+            if together:                           # tables stay with the rank that owns their partition (q % world)
+                eng.load_tables_sharded(parts)
                 shard.barrier(device)
             else:
                 for p in parts:                    # preloadTables: resident in HBM, reported as Time_load by the reference
@@ -356,7 +452,7 @@ def main():
         # workload is not the profiled one
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.universities == 100 and args.partitions == 8:
+        if os.path.exists(pmc_path) and total_univ == 100 and world == 1 and args.partitions == 8:
             pmc = json.load(open(pmc_path))
             names = [w for w in dom.replace("+", " ").split() if w.startswith("k_")]
             if names and all(nm in pmc for nm in names):
@@ -373,9 +469,11 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "LUBM-%d per GPU (%d triples, %.2f GB of N-Triples text per GPU), %d first-level partitions, "
-                                   "13 LUBM queries (Q1-Q12, Q14)" % (args.universities, n_triples, n_bytes / 1e9, args.partitions),
-                       "parallelism": ("one dictionary over all ranks, first-level partitions owned by rank, triples and join inputs exchanged"
+            "config": {"workload": "LUBM-%d (%d triples in total; rank 0's share: %d triples, %.2f GB of N-Triples text), %d first-level "
+                                   "partitions, 13 LUBM queries (Q1-Q12, Q14)" % (total_univ, total_triples, n_triples, n_bytes / 1e9, args.partitions),
+                       "parallelism": ("one data set over %d GPUs: text split by university, one dictionary over all ranks, first-level "
+                                       "partition q owned by rank q %% %d, triples routed to the owners, join inputs exchanged by key or the "
+                                       "small side sent to all; communicator: %s" % (world, world, comm_kind)
                                        if together else "independent university blocks per GPU, no cross-GPU exchange") if world > 1 else "single GPU"},
             # the metric has two halves: `value` is input triples / wall time of the partitioner calls of the timed
             # steps (slowest rank); the 13 queries of the same steps are reported as query_geomean_ms; ms_per_step covers both
@@ -398,6 +496,9 @@ def main():
                                         "cc_groups": measures["n_cc"], "cc_rows": measures["n_cc_rows"]}
         if sharded is not None:
             out["sharded_queries"] = sharded
+        if crosscheck is not None:
+            out["counts_equal_single_gpu"] = {"verified_on": "LUBM-%d partitioned and queried by all ranks together vs by rank 0 alone" % crosscheck[0],
+                                              "counts": crosscheck[1]}
         if not args.no_cpu_baseline and world == 1:  # timed beside the single-GPU run only: the other ranks would wait for it
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -212,24 +212,31 @@ void dx_result_free(dx_result* r);
  * filters run where the table lives, and before each join both inputs are redistributed by a hash of the
  * join key. This is the exchange Spark plans inside spark.sqlContext.sql (QueryProcessor.scala:187,192,
  * spark.sql.shuffle.partitions :124,139), with the GPUs of the node in the place of its shuffle partitions.
- * The library does not open connections itself: the host hands it three collectives (over RCCL in
- * production, anything else in tests). Buffers passed to `exchange` are device memory of this rank's GPU;
- * the call returns when recv_dev is complete. Counts are in elements, grouped by peer in rank order. */
+ * The library asks five collectives of a communicator (struct dx_comm). dx_comm_rccl_init makes one over RCCL
+ * inside the library (production: xGMI between the GPUs of a node); a host may hand in its own instead with
+ * dx_set_comm (the tests run two ranks over gloo that way). Buffers named *_dev are device memory of this rank's
+ * GPU. Counts are in elements, grouped by peer in rank order. */
 typedef struct dx_comm {
   int rank, world;
   void* user;
-  /* recv[p] = the value peer p passed as send[rank] */
-  int (*exchange_counts)(void* user, const uint64_t* send, uint64_t* recv);
+  /* all-to-all of small host vectors: send and recv hold `world` groups of n words; recv group p = the group
+   * peer p passed at position `rank`. n <= 16. Returns when recv is complete. */
+  int (*exchange_host)(void* user, const uint64_t* send, uint64_t* recv, int n);
   /* all-to-all with per-peer counts of elements of elem_bytes bytes */
   int (*exchange)(void* user, const void* send_dev, const uint64_t* send_counts, void* recv_dev, const uint64_t* recv_counts,
                   int elem_bytes);
-  /* element-wise sum over all ranks, result on every rank */
+  /* element-wise sum of n <= 1024 host values over all ranks, result on every rank */
   int (*allreduce_sum)(void* user, uint64_t* values, int n);
   /* the partitioner's collectives (may be NULL when only queries run on several GPUs):
    * recv_dev = the ranks' send buffers one after another in rank order (recv_counts[p] elements from p) */
   int (*allgather)(void* user, const void* send_dev, uint64_t send_count, void* recv_dev, const uint64_t* recv_counts, int elem_bytes);
   /* element-wise sum of a device array of n elements of 1 or 8 bytes, in place, result on every rank */
   int (*allreduce_sum_dev)(void* user, void* dev, uint64_t n, int elem_bytes);
+  /* 0: the three device collectives return when their result is complete, and the library waits for its own
+   *    stream before it calls them.
+   * 1: they are queued on the context's stream like kernels (the library neither waits before nor assumes
+   *    completion after; it synchronises the stream where it needs a result on the host). */
+  int stream_ordered;
 } dx_comm;
 /* comm == NULL or world == 1 returns the context to single-GPU execution.
  * With a communicator that has all five collectives, dx_partition_device / dx_partition_file are collective
@@ -238,6 +245,26 @@ typedef struct dx_comm {
  * partitions q with q % world == r of the whole input, as partitionClusters' CustomPartitioner routes
  * them (DAP.scala:541-551), with their VP tables and VP index, and its share of the node index. */
 int dx_set_comm(dx_ctx* ctx, const dx_comm* comm);
+/* The communicator over RCCL, made inside the library (replaces the executors' shuffle service Spark brings up
+ * with the session, QueryProcessor.scala:116-154, DAP.scala:41-48). Rank 0 makes a unique id and hands its
+ * DX_RCCL_ID_BYTES bytes to the other ranks by any means; then every rank calls dx_comm_rccl_init with its own
+ * context (one GPU per rank; the call returns when all `world` ranks have made it). dx_comm_rccl_init_file does
+ * both over a path all ranks can reach: rank 0 writes the id there, the others wait up to timeout_ms for it.
+ * The collectives are queued on the context's stream. dx_set_comm(ctx, NULL), another dx_comm_rccl_init and
+ * dx_free leave the group. world == 1 is single-GPU execution. */
+#define DX_RCCL_ID_BYTES 128
+int dx_rccl_unique_id(unsigned char id[DX_RCCL_ID_BYTES]);
+int dx_comm_rccl_init(dx_ctx* ctx, const unsigned char id[DX_RCCL_ID_BYTES], int rank, int world);
+int dx_comm_rccl_init_file(dx_ctx* ctx, const char* path, int rank, int world, int timeout_ms);
+/* Drives each of the communicator's collectives once with known patterns on small device buffers and checks
+ * what arrives (a collective call; every rank checks its own share). Meant to be called once after the group has
+ * been formed, before a long job relies on it. DX_E_IO with the first mismatch in dx_last_error. */
+int dx_comm_selftest(dx_ctx* ctx);
+/* preloadTables (QueryProcessor.scala:210-236) on several GPUs, a collective call: every rank passes the same
+ * `partitions` line; the tables of first-level partition q are loaded on rank q % world (CustomPartitioner's
+ * placement, DAP.scala:541-551) and declared remote elsewhere, and the owners' row and distinct counts are
+ * shared, so that every rank plans alike. rows_total = rows loaded over all ranks (the reference's Load_data). */
+int dx_load_tables_sharded(dx_ctx* ctx, const char* const* partition_keys, int n_keys, uint64_t* rows_total);
 /* A table of the `partitions` line that another rank holds (same key syntax as dx_load_table). */
 int dx_declare_remote_table(dx_ctx* ctx, const char* partition_key);
 /* Rows, distinct subjects and distinct objects of a table: read them where it is loaded, sum or share them

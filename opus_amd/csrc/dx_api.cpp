@@ -149,6 +149,34 @@ bool utf16_less(const uint8_t* a, size_t la, const uint8_t* b, size_t lb) {
 }
 
 }  // namespace
+
+void throw_if_any_failed(dx_ctx* ctx, const LocalError& mine, const std::vector<int>& codes) {
+  (void)ctx;
+  int worst = -1;
+  for (int c : codes)
+    if (c != 0 && (worst < 0 || err_slot(c) < worst)) worst = err_slot(c);
+  if (mine && (worst < 0 || err_slot(mine.code) < worst)) worst = err_slot(mine.code);
+  if (worst < 0) return;
+  const int code = err_code_of_slot(worst);
+  if (mine && err_slot(mine.code) == worst) throw AgreedError(code, mine.msg);
+  throw AgreedError(code, std::string("another rank failed (error ") + std::to_string(code) + "); this rank stops with it" +
+                          (mine ? "; its own failure: " + mine.msg : std::string()));
+}
+
+void agree_or_throw(dx_ctx* ctx, const LocalError& err) {
+  const dx_comm& cm = ctx->comm;
+  if (cm.world <= 1) {
+    if (err) throw AgreedError(err.code, err.msg);
+    return;
+  }
+  uint64_t v[kErrSlots] = {0};
+  if (err) v[err_slot(err.code)] = 1;
+  if (cm.allreduce_sum(cm.user, v, kErrSlots) != 0) throw DxError(DX_E_IO, "collective failed: allreduce_sum (agreement on errors)");
+  std::vector<int> codes;
+  for (int s = 0; s < kErrSlots; ++s)
+    if (v[s]) codes.push_back(err_code_of_slot(s));
+  throw_if_any_failed(ctx, err, codes);
+}
 }  // namespace dx
 
 using namespace dx;
@@ -179,6 +207,7 @@ void dx_free(dx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  rccl_comm_destroy(ctx);
   ctx->catalog.clear();
   ctx->part = PartitionState();
   ctx->dict = Dictionary();
@@ -638,6 +667,14 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
     const std::string dd = B + D + "_data/dx_dictionary";
     const std::string offs = read_file(dd + "/offsets.bin"), terms = read_file(dd + "/terms.bin");
     if (offs.size() < 8 || offs.size() % 8) throw DxError(DX_E_IO, "corrupt dictionary offsets");
+    {  // the kernels index the term pool by these: they must start at 0, never decrease and end at the pool's size
+      const uint64_t* o = reinterpret_cast<const uint64_t*>(offs.data());
+      const size_t n = offs.size() / 8 - 1;
+      if (n >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 terms");
+      bool ok = o[0] == 0 && o[n] == terms.size();
+      for (size_t i = 0; ok && i < n; ++i) ok = o[i] <= o[i + 1];
+      if (!ok) throw DxError(DX_E_IO, "corrupt dictionary: offsets.bin does not describe terms.bin");
+    }
     ctx->catalog.clear();
     ctx->table_stats.clear();
     ctx->part = PartitionState();
@@ -680,9 +717,16 @@ static void load_from_disk(dx_ctx* ctx, const std::string& key, CatalogTable& t)
     if (b.size() < sizeof(ColHeader)) throw DxError(DX_E_IO, "corrupt " + f);
     ColHeader h;
     memcpy(&h, b.data(), sizeof h);
-    if (memcmp(h.magic, kMagic, 8) || h.ncols < 2 || b.size() != sizeof h + h.rows * h.ncols * 8) throw DxError(DX_E_IO, "corrupt " + f);
+    if (memcmp(h.magic, kMagic, 8) || h.ncols < 2 || h.ncols > 3 || h.rows >= (1ull << 32) || b.size() != sizeof h + h.rows * h.ncols * 8)
+      throw DxError(DX_E_IO, "corrupt " + f);
+    // ids index the dictionary: none may lie outside it
+    const int64_t* v = reinterpret_cast<const int64_t*>(b.data() + sizeof h);
+    const uint64_t nt = ctx->dict.n_terms;
+    for (uint64_t i = 0; i < 2 * h.rows; ++i)
+      if ((uint64_t)v[i] >= nt) throw DxError(DX_E_IO, "corrupt " + f + ": term id outside the dictionary");
     rows += h.rows;
   }
+  if (rows >= (1ull << 32)) throw DxError(DX_E_RANGE, "table with 2^32 rows or more");
   t.own_s = DevBuf<int64_t>(ctx->pool, rows);
   t.own_o = DevBuf<int64_t>(ctx->pool, rows);
   uint64_t at = 0;
@@ -732,8 +776,9 @@ static CatalogTable& register_table(dx_ctx* ctx, const char* partition_key) {
           t.own_o = DevBuf<int64_t>(ctx->pool, t.rows);
           uint64_t at = 0;
           for (auto& sl : t.slices) {
-            DX_HIP(hipMemcpy(t.own_s.p + at, sl.s, sl.rows * 8, hipMemcpyDeviceToDevice));
-            DX_HIP(hipMemcpy(t.own_o.p + at, sl.o, sl.rows * 8, hipMemcpyDeviceToDevice));
+            // on the context's stream: ordered with the kernels that read the copy (the stream does not wait for the null stream)
+            DX_HIP(hipMemcpyAsync(t.own_s.p + at, sl.s, sl.rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            DX_HIP(hipMemcpyAsync(t.own_o.p + at, sl.o, sl.rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
             at += sl.rows;
           }
           t.s = t.own_s.p; t.o = t.own_o.p;
@@ -834,11 +879,192 @@ int dx_load_table_ids(dx_ctx* ctx, const char* partition_key, const int64_t* s, 
 
 int dx_set_comm(dx_ctx* ctx, const dx_comm* comm) {
   return guard(ctx, [&] {
-    if (!comm || comm->world <= 1) { ctx->comm = dx_comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; return; }
-    if (comm->rank < 0 || comm->rank >= comm->world || !comm->exchange_counts || !comm->exchange || !comm->allreduce_sum)
+    rccl_comm_destroy(ctx);  // leaves a group made by dx_comm_rccl_init
+    if (!comm) { ctx->comm = dx_comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}; return; }
+    if (comm->world <= 1) {  // a group of one rank: single-GPU execution; the collectives stay callable (dx_comm_selftest)
+      ctx->comm = *comm;
+      ctx->comm.rank = 0;
+      ctx->comm.world = 1;
+      return;
+    }
+    if (comm->rank < 0 || comm->rank >= comm->world || !comm->exchange_host || !comm->exchange || !comm->allreduce_sum)
       throw DxError(DX_E_INVAL, "dx_set_comm: rank out of range or a collective is missing");
     if (comm->world > 64) throw DxError(DX_E_RANGE, "dx_set_comm: more than 64 ranks");
     ctx->comm = *comm;
+  });
+}
+
+int dx_rccl_unique_id(unsigned char id[DX_RCCL_ID_BYTES]) {
+  if (!id) return DX_E_INVAL;
+  try {
+    rccl_unique_id(id);
+    return DX_OK;
+  } catch (const DxError& e) {
+    return e.code;
+  } catch (const std::exception&) {
+    return DX_E_IO;
+  }
+}
+
+int dx_comm_rccl_init(dx_ctx* ctx, const unsigned char id[DX_RCCL_ID_BYTES], int rank, int world) {
+  return guard(ctx, [&] {
+    if (!id) throw DxError(DX_E_INVAL, "null unique id");
+    rccl_comm_create(ctx, id, rank, world);
+  });
+}
+
+int dx_comm_rccl_init_file(dx_ctx* ctx, const char* path, int rank, int world, int timeout_ms) {
+  return guard(ctx, [&] {
+    if (!path) throw DxError(DX_E_INVAL, "null path");
+    unsigned char id[DX_RCCL_ID_BYTES];
+    if (world > 1) rccl_rendezvous_file(path, rank, timeout_ms > 0 ? timeout_ms : 60000, id);
+    else rccl_unique_id(id);  // a group of one rank has nobody to meet
+    rccl_comm_create(ctx, id, rank, world);
+  });
+}
+
+int dx_comm_selftest(dx_ctx* ctx) {
+  return guard(ctx, [&] {
+    const dx_comm& cm = ctx->comm;
+    if (!cm.exchange_host || !cm.exchange || !cm.allreduce_sum || !cm.allgather || !cm.allreduce_sum_dev)
+      throw DxError(DX_E_INVAL, "no communicator with all five collectives is set");
+    const int W = cm.world, R = cm.rank;
+    hipStream_t s = ctx->stream;
+    auto fail = [&](const std::string& what) { throw DxError(DX_E_IO, "communicator self-test: " + what); };
+    auto sync_before = [&] { if (!cm.stream_ordered) DX_HIP(hipStreamSynchronize(s)); };
+    {  // host all-to-all, three words per peer
+      std::vector<uint64_t> send(3 * W), recv(3 * W, ~0ull);
+      for (int p = 0; p < W; ++p) { send[3 * p] = 1000ull * R + p; send[3 * p + 1] = 7; send[3 * p + 2] = p; }
+      if (cm.exchange_host(cm.user, send.data(), recv.data(), 3)) fail("exchange_host returned an error");
+      for (int p = 0; p < W; ++p)
+        if (recv[3 * p] != 1000ull * p + R || recv[3 * p + 1] != 7 || recv[3 * p + 2] != (uint64_t)R) fail("exchange_host: wrong words from rank " + std::to_string(p));
+    }
+    {  // host sum
+      uint64_t v[2] = {(uint64_t)R + 1, 10};
+      if (cm.allreduce_sum(cm.user, v, 2)) fail("allreduce_sum returned an error");
+      if (v[0] != (uint64_t)W * (W + 1) / 2 || v[1] != 10ull * W) fail("allreduce_sum: wrong sums");
+    }
+    for (int elem_bytes : {8, 4}) {  // device all-to-all: rank r sends p + 1 + r elements to peer p
+      std::vector<uint64_t> sc(W), rc(W);
+      uint64_t ns = 0, nr = 0;
+      for (int p = 0; p < W; ++p) { sc[p] = p + 1 + R; rc[p] = R + 1 + p; ns += sc[p]; nr += rc[p]; }
+      std::vector<uint64_t> h64(ns);
+      std::vector<uint32_t> h32(ns);
+      uint64_t at = 0;
+      for (int p = 0; p < W; ++p)
+        for (uint64_t i = 0; i < sc[p]; ++i, ++at) { h64[at] = 1000000ull * R + 1000ull * p + i; h32[at] = (uint32_t)h64[at]; }
+      DevBuf<uint8_t> send(ctx->pool, ns * elem_bytes), recv(ctx->pool, nr * elem_bytes);
+      DX_HIP(hipMemcpyAsync(send.p, elem_bytes == 8 ? (const void*)h64.data() : (const void*)h32.data(), ns * elem_bytes, hipMemcpyHostToDevice, s));
+      DX_HIP(hipMemsetAsync(recv.p, 0xEE, nr * elem_bytes, s));
+      sync_before();
+      if (cm.exchange(cm.user, send.p, sc.data(), recv.p, rc.data(), elem_bytes)) fail("exchange returned an error");
+      std::vector<uint64_t> g64(nr);
+      std::vector<uint32_t> g32(nr);
+      DX_HIP(hipMemcpyAsync(elem_bytes == 8 ? (void*)g64.data() : (void*)g32.data(), recv.p, nr * elem_bytes, hipMemcpyDeviceToHost, s));
+      DX_HIP(hipStreamSynchronize(s));
+      at = 0;
+      for (int p = 0; p < W; ++p)
+        for (uint64_t i = 0; i < rc[p]; ++i, ++at) {
+          const uint64_t want = 1000000ull * p + 1000ull * R + i;
+          if ((elem_bytes == 8 ? g64[at] : (uint64_t)g32[at]) != (elem_bytes == 8 ? want : (uint64_t)(uint32_t)want))
+            fail("exchange (" + std::to_string(elem_bytes) + "-byte elements): wrong data from rank " + std::to_string(p));
+        }
+    }
+    {  // all-gather with uneven shares: rank r contributes r + 2 words
+      std::vector<uint64_t> counts(W);
+      uint64_t total = 0;
+      for (int p = 0; p < W; ++p) { counts[p] = p + 2; total += counts[p]; }
+      std::vector<uint64_t> mine(R + 2);
+      for (int i = 0; i < R + 2; ++i) mine[i] = 100ull * R + i;
+      DevBuf<uint64_t> send(ctx->pool, mine.size()), recv(ctx->pool, total);
+      DX_HIP(hipMemcpyAsync(send.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, s));
+      DX_HIP(hipMemsetAsync(recv.p, 0xEE, total * 8, s));
+      sync_before();
+      if (cm.allgather(cm.user, send.p, mine.size(), recv.p, counts.data(), 8)) fail("allgather returned an error");
+      std::vector<uint64_t> got(total);
+      DX_HIP(hipMemcpyAsync(got.data(), recv.p, total * 8, hipMemcpyDeviceToHost, s));
+      DX_HIP(hipStreamSynchronize(s));
+      uint64_t at = 0;
+      for (int p = 0; p < W; ++p)
+        for (uint64_t i = 0; i < counts[p]; ++i, ++at)
+          if (got[at] != 100ull * p + i) fail("allgather: wrong data from rank " + std::to_string(p));
+    }
+    for (int elem_bytes : {1, 8}) {  // device sums in place
+      const uint64_t n = 300;
+      std::vector<uint8_t> h8(n);
+      std::vector<uint64_t> h64(n);
+      for (uint64_t i = 0; i < n; ++i) { h8[i] = (uint8_t)((i + R) % 3); h64[i] = (i + R) % 3 + (1ull << 40); }
+      DevBuf<uint8_t> buf(ctx->pool, n * elem_bytes);
+      DX_HIP(hipMemcpyAsync(buf.p, elem_bytes == 1 ? (const void*)h8.data() : (const void*)h64.data(), n * elem_bytes, hipMemcpyHostToDevice, s));
+      sync_before();
+      if (cm.allreduce_sum_dev(cm.user, buf.p, n, elem_bytes)) fail("allreduce_sum_dev returned an error");
+      DX_HIP(hipMemcpyAsync(elem_bytes == 1 ? (void*)h8.data() : (void*)h64.data(), buf.p, n * elem_bytes, hipMemcpyDeviceToHost, s));
+      DX_HIP(hipStreamSynchronize(s));
+      for (uint64_t i = 0; i < n; ++i) {
+        uint64_t want = 0;
+        for (int p = 0; p < W; ++p) want += (i + p) % 3 + (elem_bytes == 8 ? (1ull << 40) : 0);
+        if ((elem_bytes == 1 ? (uint64_t)h8[i] : h64[i]) != (elem_bytes == 1 ? (want & 0xFF) : want)) fail("allreduce_sum_dev: wrong sum");
+      }
+    }
+  });
+}
+
+int dx_load_tables_sharded(dx_ctx* ctx, const char* const* partition_keys, int n_keys, uint64_t* rows_total) {
+  return guard(ctx, [&] {
+    if (n_keys < 0 || (n_keys && !partition_keys)) throw DxError(DX_E_INVAL, "null key list");
+    const dx_comm& cm = ctx->comm;
+    std::vector<std::string> keys;  // each table once, in the order given
+    for (int i = 0; i < n_keys; ++i) {
+      if (!partition_keys[i]) throw DxError(DX_E_INVAL, "null key");
+      if (std::find(keys.begin(), keys.end(), partition_keys[i]) == keys.end()) keys.emplace_back(partition_keys[i]);
+    }
+    // Local part: load what this rank owns, declare the rest. A failure (a missing file) is kept for the agreement below.
+    LocalError err;
+    std::vector<CatalogTable*> mine;
+    std::vector<uint64_t> stats(3 * keys.size(), 0);
+    run_local(err, [&] {
+      for (const std::string& key : keys) {
+        char* end = nullptr;
+        const long q = strtol(key.c_str(), &end, 10);  // "00001-_3=..." -> first-level partition 1
+        if (end == key.c_str() || *end != '-' || q < 0) throw DxError(DX_E_INVAL, "table key without a partition number: " + key);
+        if (cm.world <= 1 || q % cm.world == cm.rank) {
+          mine.push_back(&register_table(ctx, key.c_str()));
+        } else if (!ctx->catalog.count(view_name(key))) {
+          CatalogTable t;
+          t.key = key;
+          t.view = view_name(key);
+          t.remote = true;
+          ctx->catalog.emplace(t.view, std::move(t));
+        }
+      }
+      table_statistics(ctx, mine);
+      size_t at = 0;
+      for (size_t i = 0; i < keys.size(); ++i) {
+        auto it = ctx->catalog.find(view_name(keys[i]));
+        if (it->second.remote) continue;
+        stats[3 * i] = it->second.rows; stats[3 * i + 1] = it->second.distinct_s; stats[3 * i + 2] = it->second.distinct_o;
+        ++at;
+      }
+      (void)at;
+    });
+    uint64_t total = 0;
+    if (cm.world > 1) {
+      agree_or_throw(ctx, err);
+      // one owner per table: the sum over the ranks is the owner's numbers
+      for (size_t at = 0; at < stats.size(); at += 1023) {
+        const int n = (int)std::min<size_t>(1023, stats.size() - at);
+        if (cm.allreduce_sum(cm.user, stats.data() + at, n) != 0) throw DxError(DX_E_IO, "collective failed: allreduce_sum of the table statistics");
+      }
+      for (size_t i = 0; i < keys.size(); ++i) {
+        CatalogTable& t = ctx->catalog.find(view_name(keys[i]))->second;
+        t.has_plan_stats = true;
+        t.plan_rows = stats[3 * i]; t.plan_distinct_s = stats[3 * i + 1]; t.plan_distinct_o = stats[3 * i + 2];
+      }
+    } else if (err) {
+      throw DxError(err.code, err.msg);
+    }
+    for (size_t i = 0; i < keys.size(); ++i) total += stats[3 * i];
+    if (rows_total) *rows_total = total;
   });
 }
 

@@ -1207,11 +1207,12 @@ k_vpi_write(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
 // counts (out == nullptr) or appends the (class, 'o', rdf:type) entries of the classes in use
 template <typename K>
 __global__ void __launch_bounds__(256)
-k_vpi_type_entries(const uint8_t* __restrict__ class_used, const uint64_t* __restrict__ Pm, uint32_t n_terms, uint32_t type_pidx,
-                   int bits_term, int bits_pred, unsigned long long* __restrict__ counter, K* __restrict__ out) {
+k_vpi_type_entries(const uint8_t* __restrict__ class_used, const uint64_t* __restrict__ Pm, uint64_t owned /*partitions this rank keeps*/,
+                   uint32_t n_terms, uint32_t type_pidx, int bits_term, int bits_pred, unsigned long long* __restrict__ counter,
+                   K* __restrict__ out) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_terms; t += gridDim.x * blockDim.x) {
     if (!class_used[t]) continue;  // all but the class terms
-    unsigned long long m = Pm[t];
+    unsigned long long m = Pm[t] & owned;
     if (!m) continue;
     const unsigned long long at = atomicAdd(counter, (unsigned long long)__popcll(m));
     if (!out) continue;
@@ -1491,7 +1492,7 @@ static size_t utf16_units(const std::string& s) {
   }
   return u;
 }
-static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514 on UTF-16 units
+static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514: replaceAll matches by code point
   std::string out;
   for (size_t i = 0; i < s.size();) {
     unsigned char c = (unsigned char)s[i];
@@ -1502,7 +1503,7 @@ static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514 
       ++i;
     } else {
       const int len = (c & 0xE0) == 0xC0 ? 2 : (c & 0xF0) == 0xE0 ? 3 : (c & 0xF8) == 0xF0 ? 4 : 1;
-      out += (len == 4) ? "__" : "_";  // one '_' per UTF-16 unit
+      out += '_';  // one '_' per code point, a supplementary character included (java.util.regex works on code points)
       i += len;
     }
   }
@@ -1644,7 +1645,7 @@ void comm_ok(int rc, const char* what) {
 // every rank's value of a host number, in rank order
 std::vector<uint64_t> gather_u64(const dx_comm& cm, uint64_t v) {
   std::vector<uint64_t> send(cm.world, v), recv(cm.world, 0);
-  comm_ok(cm.exchange_counts(cm.user, send.data(), recv.data()), "exchange_counts");
+  comm_ok(cm.exchange_host(cm.user, send.data(), recv.data(), 1), "exchange_host");
   return recv;
 }
 
@@ -1744,8 +1745,36 @@ void globalise_dictionary(dx_ctx* ctx, uint32_t n_rec, uint32_t* S, uint32_t* P,
 }
 }  // namespace
 
-void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
-                   int nparts) {
+static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes, int nparts);
+
+// With a communicator the call is collective, and a rank must not leave it alone: the body passes checkpoints
+// (agreements on "no rank has failed") before each group of collectives and at its end, and a rank whose own
+// work fails in between brings its error to the checkpoint its peers reach next. All ranks return the same code.
+void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes, int nparts) {
+  if (ctx->comm.world <= 1) {
+    run_partition_body(ctx, text, n_bytes, classes, nparts);
+    return;
+  }
+  LocalError err;
+  try {
+    run_partition_body(ctx, text, n_bytes, classes, nparts);
+    return;
+  } catch (const AgreedError&) {
+    ctx->part = PartitionState();
+    throw;
+  } catch (const DxError& e) {
+    err.code = e.code; err.msg = e.what();
+  } catch (const HipError& e) {
+    err.code = DX_E_HIP; err.msg = e.what();
+  } catch (const std::bad_alloc&) {
+    err.code = DX_E_NOMEM; err.msg = "host allocation failed";
+  }
+  ctx->part = PartitionState();
+  agree_or_throw(ctx, err);
+}
+
+static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
+                               int nparts) {
   hipStream_t s = ctx->stream;
   DevPool& pool = ctx->pool;
   if (nparts < 1 || nparts > DX_MAX_PARTITIONS) throw DxError(DX_E_INVAL, "n_partitions must be in [1, 64]");
@@ -1879,8 +1908,12 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   const dx_comm& cm = ctx->comm;
   const bool sharded = cm.world > 1;
   uint64_t owned = ~0ull;  // first-level partitions this rank keeps
+  // Agreement that no rank has failed so far (a collective; does nothing on one GPU). A rank that fails between two
+  // of these brings its error to the next one from run_partition's handler.
+  auto checkpoint = [&] { if (sharded) agree_or_throw(ctx, LocalError{}); };
   if (sharded) {
     if (!cm.allgather || !cm.allreduce_sum_dev) throw DxError(DX_E_INVAL, "the communicator lacks the partitioner's collectives");
+    checkpoint();  // malformed input, dictionary limits, anything of the local passes above
     owned = 0;
     for (int q = 0; q < nparts; ++q)
       if (q % cm.world == cm.rank) owned |= 1ull << q;
@@ -2012,7 +2045,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     std::vector<unsigned long long> cur(cm.world);
     unsigned long long run = 0;
     for (int p = 0; p < cm.world; ++p) { send[p] = h[p]; cur[p] = run; run += h[p]; }
-    if (run >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 routed triples on one GPU");
+    if (run >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 routed triples on one GPU");  // reaches the checkpoint below from the handler
     DX_HIP(hipMemcpyAsync(counts.p + DX_MAX_PARTITIONS, cur.data(), sizeof(unsigned long long) * cm.world, hipMemcpyHostToDevice, s));
     DevBuf<uint64_t> outbox(pool, run);
     if (n_rec)
@@ -2020,10 +2053,15 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
                          counts.p + DX_MAX_PARTITIONS, outbox.p);
     DX_HIP(hipStreamSynchronize(s));
     DX_HIP(hipGetLastError());
-    comm_ok(cm.exchange_counts(cm.user, send.data(), recv.data()), "exchange_counts");
+    checkpoint();
+    comm_ok(cm.exchange_host(cm.user, send.data(), recv.data(), 1), "exchange_host");
     uint64_t n_in = 0;
     for (int p = 0; p < cm.world; ++p) n_in += recv[p];
-    if (n_in >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 triples arrive on one GPU");
+    {  // an inbox of 2^32 triples is this rank's problem alone: all ranks hear of it before the triples move
+      LocalError e;
+      if (n_in >= (1ull << 32)) { e.code = DX_E_RANGE; e.msg = "more than 2^32 triples arrive on one GPU"; }
+      agree_or_throw(ctx, e);
+    }
     DevBuf<uint64_t> inbox(pool, n_in);
     comm_ok(cm.exchange(cm.user, outbox.p, send.data(), inbox.p, recv.data(), 8), "exchange of the triples");
     ps.local_keys = std::move(ps.uniq);
@@ -2073,7 +2111,10 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
     h_counters[1] = v[1];
     too_many_rows = v[2];
   }
-  if (too_many_rows) throw DxError(DX_E_RANGE, "more than 2^32 rows over the first-level partitions of one GPU");
+  if (too_many_rows) {  // with several ranks the sum above has told all of them
+    if (sharded) throw AgreedError(DX_E_RANGE, "more than 2^32 rows over the first-level partitions of one GPU");
+    throw DxError(DX_E_RANGE, "more than 2^32 rows over the first-level partitions of one GPU");
+  }
   st.n_unique = h_counters[0];
   st.n_edges = h_counters[1];
   const uint32_t n_rows = h_part_base[nparts];
@@ -2138,7 +2179,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
                        ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p);
     exclusive_scan_u8_u32(pool, es.p, pos_s.p, n_rows, totals.p, s);
     exclusive_scan_u8_u32(pool, eo.p, pos_o.p, n_rows, totals.p + 1, s);
-    hipLaunchKernelGGL(k_vpi_type_entries<uint64_t>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx,
+    hipLaunchKernelGGL(k_vpi_type_entries<uint64_t>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, owned, n_terms, ps.type_pidx,
                        bits_term, bits_pred, n_type_ent.p, (uint64_t*)nullptr);
     DevBuf<uint32_t> sb(pool, nparts + 1);
     hipLaunchKernelGGL(k_vpi_s_bases, dim3(1), dim3(128), 0, s, pos_s.p, d_part_base.p, nparts, n_rows, totals.p, sb.p);
@@ -2162,7 +2203,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
       hipLaunchKernelGGL(k_vpi_write<K>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts, bits_term,
                          bits_pred, es.p, eo.p, pos_s.p, pos_o.p, ps.vpi_s.p, ent.p);
       if (h_type_ent)
-        hipLaunchKernelGGL(k_vpi_type_entries<K>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, n_terms, ps.type_pidx,
+        hipLaunchKernelGGL(k_vpi_type_entries<K>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, owned, n_terms, ps.type_pidx,
                            bits_term, bits_pred, n_type_ent.p + 1, ent.p + h_tot[1]);
       es.reset(); eo.reset(); pos_s.reset(); pos_o.reset();
       if constexpr (sizeof(K) == 4) radix_sort_u32(pool, ent, n_o_raw, ent_bits, s);
@@ -2185,6 +2226,7 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   tm.mark();
   fetch.sync();
   DX_HIP(hipGetLastError());
+  checkpoint();  // every rank got through: all return success together
   if (n_rows)
     for (int q = 0; q <= nparts; ++q) ps.vpi_o_base[q] = hvb[q];
 

@@ -572,8 +572,10 @@ void launch_probe(hipStream_t s, uint64_t rows, const ProbeArgs& p) {
 }  // namespace
 
 // Pinned host block the final counters land in.
+constexpr int kShardedWords = 2 * 64 + 8;
 struct QueryHostBlock {
   unsigned long long counters[MAXSTEPS + 2];
+  unsigned long long sharded[kShardedWords];  // several GPUs: row counts per destination rank on their way to the host
 };
 
 // The pinned block and the two events a statement uses, made once per context (dx_init): no statement creates
@@ -852,27 +854,61 @@ uint64_t run_query_count_noalloc(dx_ctx* ctx, const std::string& sql) {
 
 
 // ---- several GPUs -------------------------------------------------------------------------------------
+// One context per GPU; a table lives on the rank that owns its first-level partition. Per join step the two
+// inputs must meet: the filtered rows of the new table (the arm, A) and the running intermediate (I), which
+// is always spread over the ranks without repetition. Three ways, chosen alike on every rank:
+//   * one side is small (by the row counts the ranks exchange): every rank gets all of it (one all-gather) and
+//     joins it with its own share of the other side;
+//   * otherwise both sides are redistributed by a hash of the join key (the intermediate only if it is not
+//     spread by that key already): one all-to-all per relation with all its columns packed row by row;
+//   * a cross product sends the whole arm everywhere.
+// Every step opens with one exchange of a few words between the hosts: each rank's row counts, its error state,
+// and -- when the planner's estimates say that the step will be a redistribution -- the rows it has for every
+// peer, counted ahead of the decision, so that a step costs one host exchange and one or two data collectives.
+// This is Spark's Exchange hashpartitioning under SortMergeJoin, and its broadcast of a small side
+// (QueryProcessor.scala:136-139; QueryProcessorCold.scala:105), with the node's GPUs as shuffle partitions.
+// A rank whose local work fails keeps to the protocol until the next collective, where all ranks learn of it
+// and return the same error: nobody is left waiting.
 namespace {
 
 constexpr int kMaxWorld = 64;
+// rows over all ranks up to which a side is sent to every rank instead of hashed (DX_SMALL_SIDE_ROWS overrides it:
+// 0 makes every join a redistribution, which is how the tests reach that path on small data)
+uint64_t small_side_rows() {
+  const char* e = getenv("DX_SMALL_SIDE_ROWS");
+  return e && *e ? strtoull(e, nullptr, 10) : 16384;
+}
 
-// dest[i] = rank that owns row i's join key; counts[p] = rows going to rank p
-struct ShuffleKeys {
+struct DevRel {  // a relation on this rank: columns + row count on the device; the host's count once it is known
+  std::vector<DevBuf<int64_t>> own;
+  int64_t* col[MAXC] = {};
+  int ncols = 0;
+  uint64_t cap = 0;
+  uint64_t rows = 0;                  // valid when rows_known
+  bool rows_known = false;
+  DevBuf<unsigned long long> count;   // device copy of the row count
+};
+
+struct KeyCols {
   const int64_t* k0;
   const int64_t* k1;  // nullptr for a one-column key
-  uint32_t rows;
+  const unsigned long long* count;
+  uint32_t cap;
   int world;
 };
-__device__ __forceinline__ uint32_t key_owner(const ShuffleKeys& k, uint32_t i) {
+__device__ __forceinline__ uint32_t key_owner(const KeyCols& k, uint32_t i) {
   const uint64_t h = k.k1 ? hash_key2(k.k0[i], k.k1[i]) : hash_key(k.k0[i]);
   return (uint32_t)((h >> 32) % (uint32_t)k.world);  // the join's hash table takes the low bits
 }
+// dest[i] = rank that owns row i's join key; counts[p] += rows going to rank p
 __global__ void __launch_bounds__(256)
-k_shuffle_count(ShuffleKeys k, uint8_t* __restrict__ dest, unsigned long long* __restrict__ counts) {
+k_shuffle_count(KeyCols k, uint8_t* __restrict__ dest, unsigned long long* __restrict__ counts) {
   __shared__ uint32_t c[kMaxWorld];
   if (threadIdx.x < kMaxWorld) c[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < k.rows; i += gridDim.x * blockDim.x) {
+  const unsigned long long n64 = *k.count;
+  const uint32_t rows = n64 < k.cap ? (uint32_t)n64 : k.cap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
     const uint32_t d = key_owner(k, i);
     dest[i] = (uint8_t)d;
     atomicAdd(&c[d], 1u);
@@ -880,15 +916,16 @@ k_shuffle_count(ShuffleKeys k, uint8_t* __restrict__ dest, unsigned long long* _
   __syncthreads();
   if (threadIdx.x < k.world && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c[threadIdx.x]);
 }
-// Rows grouped by destination, one column at a time per row; positions come from one atomic per wave and
-// destination present in it.
-struct ShuffleCols {
+
+struct RowCols {
   const int64_t* in[MAXC];
-  int64_t* out[MAXC];
   int ncols;
 };
+// Rows grouped by destination and packed row by row (ncols consecutive words per row): what one all-to-all
+// carries. Positions come from one atomic per wave and destination present in it.
 __global__ void __launch_bounds__(256)
-k_shuffle_scatter(ShuffleCols sc, const uint8_t* __restrict__ dest, uint32_t rows, int world, unsigned long long* __restrict__ cursor) {
+k_shuffle_scatter(RowCols rc, const uint8_t* __restrict__ dest, uint32_t rows, int world, unsigned long long* __restrict__ cursor,
+                  int64_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -908,261 +945,400 @@ k_shuffle_scatter(ShuffleCols sc, const uint8_t* __restrict__ dest, uint32_t row
       if (d == (uint32_t)p) pos = base + __popcll(b & lt);
     }
     if (valid)
-      for (int c = 0; c < sc.ncols; ++c) sc.out[c][pos] = sc.in[c][i];
+      for (int c = 0; c < rc.ncols; ++c) out[pos * rc.ncols + c] = rc.in[c][i];
   }
 }
-
-struct LocalRel {  // a relation whose row count the host knows
-  std::vector<DevBuf<int64_t>> own;
-  int64_t* col[MAXC] = {};
-  int ncols = 0;
-  uint64_t rows = 0;
+// columns -> packed rows (first `rows` rows), and back
+__global__ void __launch_bounds__(256) k_pack_rows(RowCols rc, uint32_t rows, int64_t* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x)
+    for (int c = 0; c < rc.ncols; ++c) out[(uint64_t)i * rc.ncols + c] = rc.in[c][i];
+}
+struct ColsOut {
+  int64_t* out[MAXC];
+  int ncols;
 };
+__global__ void __launch_bounds__(256) k_unpack_rows(const int64_t* __restrict__ in, uint32_t rows, ColsOut co) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x)
+    for (int c = 0; c < co.ncols; ++c) co.out[c][i] = in[(uint64_t)i * co.ncols + c];
+}
+__global__ void k_set_count(unsigned long long* p, unsigned long long v) { *p = v; }
 
 void comm_check(int rc, const char* what) {
   if (rc != 0) throw DxError(DX_E_IO, std::string("collective failed: ") + what);
 }
 
-// Redistributes `in` so that rows with equal key columns meet on one rank (nkey == 0: every rank gets every row).
-LocalRel shuffle(dx_ctx* ctx, const LocalRel& in, int nkey, const int* key_col) {
-  const dx_comm& cm = ctx->comm;
-  hipStream_t s = ctx->stream;
-  DevPool& pool = ctx->pool;
-  const int W = cm.world;
-  std::vector<uint64_t> send(W, 0), recv(W, 0);
-  LocalRel grouped;
-  grouped.ncols = in.ncols;
-  const uint64_t copies = nkey == 0 ? (uint64_t)W : 1;
-  if (in.rows * copies >= (1ull << 32)) throw DxError(DX_E_RANGE, "shuffle of 2^32 rows or more");
-  for (int c = 0; c < in.ncols; ++c) { grouped.own.emplace_back(pool, std::max<uint64_t>(in.rows * copies, 1)); grouped.col[c] = grouped.own.back().p; }
-  if (nkey == 0) {
-    for (int p = 0; p < W; ++p) {
-      send[p] = in.rows;
-      for (int c = 0; c < in.ncols && in.rows; ++c)
-        DX_HIP(hipMemcpyAsync(grouped.col[c] + (uint64_t)p * in.rows, in.col[c], in.rows * 8, hipMemcpyDeviceToDevice, s));
-    }
-  } else if (in.rows) {
-    DevBuf<uint8_t> dest(pool, in.rows);
-    DevBuf<unsigned long long> counts(pool, 2 * kMaxWorld);
-    DX_HIP(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * 2 * kMaxWorld, s));
-    ShuffleKeys sk{in.col[key_col[0]], nkey == 2 ? in.col[key_col[1]] : nullptr, (uint32_t)in.rows, W};
-    hipLaunchKernelGGL(k_shuffle_count, dim3(scan_grid(in.rows)), dim3(256), 0, s, sk, dest.p, counts.p);
-    std::vector<unsigned long long> h(W);
-    DX_HIP(hipMemcpyAsync(h.data(), counts.p, sizeof(unsigned long long) * W, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
+struct ShardedRun {
+  dx_ctx* ctx;
+  const dx_comm& cm;
+  hipStream_t s;
+  DevPool& pool;
+  LocalError err;  // this rank's outcome so far
+  int W;
+  uint64_t* pinned;  // the context's pinned block (counters of a statement)
+  int n_host_exchanges = 0, n_data_collectives = 0;
+
+  explicit ShardedRun(dx_ctx* c) : ctx(c), cm(c->comm), s(c->stream), pool(c->pool), W(c->comm.world) {
+    pinned = reinterpret_cast<uint64_t*>(static_cast<QueryHostBlock*>(ctx->q_host)->sharded);
+  }
+  void before_collective() {  // a communicator that works outside the context's stream must find the buffers complete
+    if (!cm.stream_ordered) DX_HIP(hipStreamSynchronize(s));
+  }
+  RowCols row_cols(const DevRel& r) const {
+    RowCols rc{};
+    rc.ncols = r.ncols;
+    for (int c = 0; c < r.ncols; ++c) rc.in[c] = r.col[c];
+    return rc;
+  }
+  DevRel make_rel(int ncols, uint64_t cap) {
+    DevRel r;
+    r.ncols = ncols;
+    r.cap = std::max<uint64_t>(cap, 1);
+    if (r.cap >= (1ull << 32)) throw DxError(DX_E_RANGE, "relation with 2^32 rows or more on one GPU");
+    for (int c = 0; c < ncols; ++c) { r.own.emplace_back(pool, r.cap); r.col[c] = r.own.back().p; }
+    r.count = DevBuf<unsigned long long>(pool, 1);
+    return r;
+  }
+  void set_rows(DevRel& r, uint64_t rows) {
+    r.rows = rows;
+    r.rows_known = true;
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, r.count.p, (unsigned long long)rows);  // the kernels read the count on the device
+  }
+
+  // Every rank gets all rows of `in` (row counts of all ranks known). Collective.
+  DevRel allgather_rel(const DevRel& in, const std::vector<uint64_t>& rows_by_rank) {
+    uint64_t total = 0;
+    std::vector<uint64_t> counts(W);
+    for (int r = 0; r < W; ++r) { counts[r] = rows_by_rank[r] * in.ncols; total += rows_by_rank[r]; }
+    if (total >= (1ull << 32)) throw DxError(DX_E_RANGE, "broadcast of 2^32 rows or more");  // same totals on every rank
+    DevBuf<int64_t> send(pool, std::max<uint64_t>(in.rows * in.ncols, 1)), recv(pool, std::max<uint64_t>(total * in.ncols, 1));
+    if (in.rows) hipLaunchKernelGGL(k_pack_rows, dim3(scan_grid(in.rows)), dim3(256), 0, s, row_cols(in), (uint32_t)in.rows, send.p);
+    before_collective();
+    comm_check(cm.allgather(cm.user, send.p, in.rows * in.ncols, recv.p, counts.data(), 8), "allgather of a relation");
+    ++n_data_collectives;
+    DevRel full = make_rel(in.ncols, total);
+    ColsOut co{};
+    co.ncols = in.ncols;
+    for (int c = 0; c < in.ncols; ++c) co.out[c] = full.col[c];
+    if (total) hipLaunchKernelGGL(k_unpack_rows, dim3(scan_grid(total)), dim3(256), 0, s, recv.p, (uint32_t)total, co);
+    set_rows(full, total);
+    return full;
+  }
+
+  // Rows of `in` to the ranks `dest` names: send_counts from this rank's count kernel, recv_counts from the peers'.
+  DevRel exchange_rel(const DevRel& in, const uint8_t* dest, const std::vector<uint64_t>& send_rows, const std::vector<uint64_t>& recv_rows) {
+    uint64_t n_out = 0, n_in = 0;
+    std::vector<uint64_t> sc(W), rc(W);
     std::vector<unsigned long long> cur(W);
-    unsigned long long run = 0;
-    for (int p = 0; p < W; ++p) { send[p] = h[p]; cur[p] = run; run += h[p]; }
-    DX_HIP(hipMemcpyAsync(counts.p + kMaxWorld, cur.data(), sizeof(unsigned long long) * W, hipMemcpyHostToDevice, s));
-    ShuffleCols sc{};
-    sc.ncols = in.ncols;
-    for (int c = 0; c < in.ncols; ++c) { sc.in[c] = in.col[c]; sc.out[c] = grouped.col[c]; }
-    hipLaunchKernelGGL(k_shuffle_scatter, dim3(scan_grid(in.rows)), dim3(256), 0, s, sc, dest.p, (uint32_t)in.rows, W, counts.p + kMaxWorld);
+    for (int p = 0; p < W; ++p) { cur[p] = n_out; n_out += send_rows[p]; n_in += recv_rows[p]; sc[p] = send_rows[p] * in.ncols; rc[p] = recv_rows[p] * in.ncols; }
+    DevBuf<int64_t> send(pool, std::max<uint64_t>(n_out * in.ncols, 1)), recv(pool, std::max<uint64_t>(n_in * in.ncols, 1));
+    DevBuf<unsigned long long> cursor(pool, kMaxWorld);
+    memcpy(pinned, cur.data(), 8 * W);
+    DX_HIP(hipMemcpyAsync(cursor.p, pinned, 8 * W, hipMemcpyHostToDevice, s));
+    if (n_out) hipLaunchKernelGGL(k_shuffle_scatter, dim3(scan_grid(n_out)), dim3(256), 0, s, row_cols(in), dest, (uint32_t)n_out, W, cursor.p, send.p);
+    before_collective();
+    comm_check(cm.exchange(cm.user, send.p, sc.data(), recv.p, rc.data(), 8), "exchange of a relation");
+    ++n_data_collectives;
+    DevRel out = make_rel(in.ncols, n_in);
+    ColsOut co{};
+    co.ncols = in.ncols;
+    for (int c = 0; c < in.ncols; ++c) co.out[c] = out.col[c];
+    if (n_in) hipLaunchKernelGGL(k_unpack_rows, dim3(scan_grid(n_in)), dim3(256), 0, s, recv.p, (uint32_t)n_in, co);
+    set_rows(out, n_in);
+    return out;
   }
-  DX_HIP(hipStreamSynchronize(s));
-  DX_HIP(hipGetLastError());
-  comm_check(cm.exchange_counts(cm.user, send.data(), recv.data()), "exchange_counts");
-  LocalRel out;
-  out.ncols = in.ncols;
-  for (int p = 0; p < W; ++p) out.rows += recv[p];
-  if (out.rows >= (1ull << 32)) throw DxError(DX_E_RANGE, "shuffle of 2^32 rows or more");
-  for (int c = 0; c < in.ncols; ++c) {
-    out.own.emplace_back(pool, std::max<uint64_t>(out.rows, 1));
-    out.col[c] = out.own.back().p;
-    comm_check(cm.exchange(cm.user, grouped.col[c], send.data(), out.col[c], recv.data(), 8), "exchange");
-  }
-  return out;
-}
+};
 
 }  // namespace
 
-// The plan of run_query, executed by all ranks together. Differences: every arm is filtered and materialised
-// where its table lives; before a join, the arm's rows and (unless it is already spread by the same
-// variables) the intermediate are redistributed by a hash of the join key; row counts are read back after
-// every step, because the exchanges need them on the host.
+// The plan of run_query, executed by all ranks together (every rank passes the same statement).
 dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode) {
   const dx_comm& cm = ctx->comm;
   if (cm.world > kMaxWorld) throw DxError(DX_E_RANGE, "more than 64 ranks");
+  if (!ctx->q_host) throw DxError(DX_E_INVAL, "context was not set up for queries");
+  // The statement text is the same on every rank, so a parse error is every rank's error: no collective needed.
   const SqlQuery q = parse_sql(sql);
-  Plan plan = make_plan(ctx, q);
-  if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
+  const int nsteps = (int)q.subs.size();
+  if (nsteps > MAXSTEPS) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 30 sub-selects");
+  ShardedRun run(ctx);
+  LocalError& err = run.err;
   hipStream_t s = ctx->stream;
   DevPool& pool = ctx->pool;
-  const int nsteps = (int)plan.rels.size();
-  ConstArgs ca;
-  ca.n = (int)plan.const_str.size();
-  uint32_t off = 0;
-  for (int i = 0; i < ca.n; ++i) {
-    ca.off[i] = off;
-    ca.preset[i] = plan.const_preset[i];
-    if (off + plan.const_str[i].size() > (size_t)kConstBytes) throw DxError(DX_E_UNSUPPORTED, "SQL: constants exceed 2.5 KiB in total");
-    memcpy(ca.bytes + off, plan.const_str[i].data(), plan.const_str[i].size());
-    ca.hash[i] = hash_bytes((const uint8_t*)plan.const_str[i].data(), plan.const_str[i].size(), ctx->dict.seed);
-    off += (uint32_t)plan.const_str[i].size();
-  }
-  ca.off[ca.n] = off;
+  const int W = cm.world;
+  const uint64_t kSmallSideRows = small_side_rows();
+  // From here on a failure may be this rank's alone (a table it was not told about, a buffer that does not fit):
+  // it is carried to the next collective instead of thrown.
+  Plan plan;
+  ConstArgs ca{};
   DevBuf<int64_t> consts(pool, kMaxConsts);
-  DevBuf<unsigned long long> counter(pool, 1);
-  if (ca.n)
-    hipLaunchKernelGGL(k_resolve_consts, dim3(ca.n), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
-                       ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
-  auto read_counter = [&]() {
-    unsigned long long h = 0;
-    DX_HIP(hipMemcpyAsync(&h, counter.p, 8, hipMemcpyDeviceToHost, s));
-    DX_HIP(hipStreamSynchronize(s));
-    DX_HIP(hipGetLastError());
-    return (uint64_t)h;
-  };
-  // filtered, projected rows of a sub-select's arms that live here
+  run_local(err, [&] {
+    plan = make_plan(ctx, q);
+    if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
+    ca.n = (int)plan.const_str.size();
+    uint32_t off = 0;
+    for (int i = 0; i < ca.n; ++i) {
+      ca.off[i] = off;
+      ca.preset[i] = plan.const_preset[i];
+      if (off + plan.const_str[i].size() > (size_t)kConstBytes) throw DxError(DX_E_UNSUPPORTED, "SQL: constants exceed 2.5 KiB in total");
+      memcpy(ca.bytes + off, plan.const_str[i].data(), plan.const_str[i].size());
+      ca.hash[i] = hash_bytes((const uint8_t*)plan.const_str[i].data(), plan.const_str[i].size(), ctx->dict.seed);
+      off += (uint32_t)plan.const_str[i].size();
+    }
+    ca.off[ca.n] = off;
+    if (ca.n)
+      hipLaunchKernelGGL(k_resolve_consts, dim3(ca.n), dim3(64), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
+                         ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p);
+  });
+  // filtered, projected rows of a sub-select's arms that live here; the row count stays on the device
   auto materialise = [&](const PlanRel& r) {
-    LocalRel a;
-    a.ncols = r.ncols;
-    const uint64_t cap = std::max<uint64_t>(r.rows_upper, 1);
+    DevRel a = run.make_rel(r.ncols, r.rows_upper);
     RelDev out{};
     out.ncols = r.ncols;
-    out.cap = (uint32_t)cap;
-    out.count = counter.p;
-    for (int c = 0; c < r.ncols; ++c) { a.own.emplace_back(pool, cap); a.col[c] = a.own.back().p; out.col[c] = a.col[c]; }
-    DX_HIP(hipMemsetAsync(counter.p, 0, 8, s));
+    out.cap = (uint32_t)a.cap;
+    out.count = a.count.p;
+    for (int c = 0; c < r.ncols; ++c) out.col[c] = a.col[c];
+    DX_HIP(hipMemsetAsync(a.count.p, 0, 8, s));
     for (const auto& arm : r.arms)
-      if (arm.t->rows) launch_scan_emit(s, arm.t->rows, arm_dev(r, arm), consts.p, out, counter.p);
-    a.rows = read_counter();
+      if (arm.t->rows) launch_scan_emit(s, arm.t->rows, arm_dev(r, arm), consts.p, out, a.count.p);
     return a;
+  };
+  auto read_rows = [&](DevRel& r) {  // row count to the host (clamped to the buffer; the caller checks for overflow itself)
+    DX_HIP(hipMemcpyAsync(&run.pinned[0], r.count.p, 8, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    DX_HIP(hipGetLastError());
+    r.rows = run.pinned[0];
+    r.rows_known = true;
   };
   auto* res = new dx_result();
   res->ctx = ctx;
-  res->names = plan.select_names;
-  res->virtual_terms = plan.virtual_terms;
   try {
     std::ostringstream explain;
-    LocalRel I;
+    DevRel I;
     std::vector<int> I_cls, I_spread;  // classes of I's columns; classes I is spread by (sorted; empty = as it fell)
     uint64_t local_count = 0;
     for (int k = 0; k < nsteps; ++k) {
-      const PlanRel& r = plan.rels[k];
       const bool last = k == nsteps - 1;
       const bool count_only = last && mode == DX_QUERY_COUNT;
-      LocalRel A = materialise(r);
-      explain << (k ? "join " : "scan ");
-      for (size_t a = 0; a < r.arms.size(); ++a)
-        explain << (a ? " UNION " : "") << r.arms[a].t->view << (r.arms[a].t->remote ? "[remote" : "[local") << ", " << r.arms[a].t->rows << " rows]";
+      DevRel A;
+      const PlanRel* r = err ? nullptr : &plan.rels[k];
+      run_local(err, [&] {
+        explain << (k ? "join " : "scan ");
+        for (size_t a = 0; a < r->arms.size(); ++a)
+          explain << (a ? " UNION " : "") << r->arms[a].t->view << (r->arms[a].t->remote ? "[remote" : "[local") << ", " << r->arms[a].t->rows << " rows]";
+        A = materialise(*r);
+      });
       if (k == 0) {
-        I = std::move(A);
-        I_cls.assign(r.cls, r.cls + r.ncols);
-        local_count = I.rows;
-        explain << " -> " << I.rows << " rows here\n";
+        run_local(err, [&] {
+          I = std::move(A);
+          I_cls.assign(r->cls, r->cls + r->ncols);
+          if (nsteps == 1) { read_rows(I); local_count = I.rows; explain << " -> " << I.rows << " rows here\n"; }
+        });
         continue;
       }
+      // ---- what joins what
       ProbeArgs pa{};
-      pa.consts = consts.p;
-      pa.nkey = 0;
-      pa.nnew = 0;
       std::vector<int> new_cls, key_cls;
-      for (int c = 0; c < r.ncols; ++c) {
-        int at = -1;
-        for (size_t j = 0; j < I_cls.size(); ++j)
-          if (I_cls[j] == r.cls[c]) at = (int)j;
-        if (at >= 0) {
-          if (pa.nkey < 2) { pa.key_src[pa.nkey] = c; pa.key_col[pa.nkey] = at; ++pa.nkey; key_cls.push_back(r.cls[c]); }
-          else throw DxError(DX_E_UNSUPPORTED, "SQL: join on three columns of one sub-select");
+      run_local(err, [&] {
+        pa.consts = consts.p;
+        for (int c = 0; c < r->ncols; ++c) {
+          int at = -1;
+          for (size_t j = 0; j < I_cls.size(); ++j)
+            if (I_cls[j] == r->cls[c]) at = (int)j;
+          if (at >= 0) {
+            if (pa.nkey < 2) { pa.key_src[pa.nkey] = c; pa.key_col[pa.nkey] = at; ++pa.nkey; key_cls.push_back(r->cls[c]); }
+            else throw DxError(DX_E_UNSUPPORTED, "SQL: join on three columns of one sub-select");
+          } else {
+            pa.new_src[pa.nnew++] = c;
+            new_cls.push_back(r->cls[c]);
+          }
+        }
+        if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
+        // both sides hash the key columns in the same order: ascending variable class
+        if (pa.nkey == 2 && key_cls[0] > key_cls[1]) {
+          std::swap(key_cls[0], key_cls[1]);
+          std::swap(pa.key_src[0], pa.key_src[1]);
+          std::swap(pa.key_col[0], pa.key_col[1]);
+        }
+        if (!I.rows_known) read_rows(I);
+      });
+      // ---- bring the two sides together. The opening exchange is the same on every path, so a rank that has
+      // failed (it may not even have a plan) can take part in it and say so.
+      const double estA = err ? 0 : r->est, estI = err ? 0 : (k - 1 < (int)plan.est_rows.size() ? plan.est_rows[k - 1] : 1e18);
+      const bool cross = !err && pa.nkey == 0;
+      const bool expect_shuffle = !err && !cross && estA > (double)kSmallSideRows && estI > (double)kSmallSideRows;
+      const bool move_I = !err && I_spread != key_cls;
+      DevBuf<uint8_t> destA(pool, err ? 1 : std::max<uint64_t>(A.cap, 1)), destI(pool, (err || !move_I) ? 1 : std::max<uint64_t>(I.rows, 1));
+      DevBuf<unsigned long long> counts(pool, 2 * kMaxWorld + 1);
+      std::vector<uint64_t> sendA(W, 0), sendI(W, 0), recvA(W, 0), recvI(W, 0);
+      auto count_destinations = [&](bool also_rows_of_A) {  // queues the count kernels and brings their results to the host
+        DX_HIP(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * (2 * kMaxWorld + 1), s));
+        KeyCols ka{A.col[pa.key_src[0]], pa.nkey == 2 ? A.col[pa.key_src[1]] : nullptr, A.count.p, (uint32_t)A.cap, W};
+        hipLaunchKernelGGL(k_shuffle_count, dim3(scan_grid(A.rows_known ? A.rows : A.cap)), dim3(256), 0, s, ka, destA.p, counts.p);
+        if (move_I && I.rows) {
+          KeyCols ki{I.col[pa.key_col[0]], pa.nkey == 2 ? I.col[pa.key_col[1]] : nullptr, I.count.p, (uint32_t)I.cap, W};
+          hipLaunchKernelGGL(k_shuffle_count, dim3(scan_grid(I.rows)), dim3(256), 0, s, ki, destI.p, counts.p + kMaxWorld);
+        }
+        if (also_rows_of_A) DX_HIP(hipMemcpyAsync(counts.p + 2 * kMaxWorld, A.count.p, 8, hipMemcpyDeviceToDevice, s));
+        DX_HIP(hipMemcpyAsync(run.pinned, counts.p, sizeof(unsigned long long) * (2 * kMaxWorld + 1), hipMemcpyDeviceToHost, s));
+        DX_HIP(hipStreamSynchronize(s));
+        DX_HIP(hipGetLastError());
+        for (int p = 0; p < W; ++p) { sendA[p] = run.pinned[p]; sendI[p] = run.pinned[kMaxWorld + p]; }
+        if (also_rows_of_A) { A.rows = run.pinned[2 * kMaxWorld]; A.rows_known = true; }
+      };
+      bool counted = false;
+      run_local(err, [&] {
+        if (std::max<uint64_t>(A.cap, I.rows) >= (1ull << 32)) throw DxError(DX_E_RANGE, "relation of 2^32 rows or more on one GPU");
+        if (expect_shuffle) { count_destinations(true); counted = true; }
+        else read_rows(A);
+      });
+      DevRel A2, I2;
+      bool have_A2 = false, have_I2 = false;
+      {
+        // per peer p: [0] rows of my arm, [1] rows of my intermediate, [2] my error code, [3] 1 = words 4 and 5 are valid,
+        // [4] rows of my arm for p, [5] rows of my intermediate for p
+        std::vector<uint64_t> send(6 * W), recv(6 * W);
+        for (int p = 0; p < W; ++p) {
+          send[6 * p] = err ? 0 : A.rows;
+          send[6 * p + 1] = err ? 0 : I.rows;
+          send[6 * p + 2] = (uint64_t)(err ? -err.code : 0);
+          send[6 * p + 3] = counted ? 1 : 0;
+          send[6 * p + 4] = sendA[p];
+          send[6 * p + 5] = sendI[p];
+        }
+        comm_check(cm.exchange_host(cm.user, send.data(), recv.data(), 6), "exchange of row counts");
+        ++run.n_host_exchanges;
+        std::vector<int> codes(W);
+        std::vector<uint64_t> a_rows(W), i_rows(W);
+        uint64_t a_tot = 0, i_tot = 0, inA = 0, inI = 0;
+        bool all_counted = true;
+        for (int p = 0; p < W; ++p) {
+          a_rows[p] = recv[6 * p]; i_rows[p] = recv[6 * p + 1]; codes[p] = -(int)recv[6 * p + 2];
+          all_counted &= recv[6 * p + 3] != 0;
+          recvA[p] = recv[6 * p + 4]; recvI[p] = recv[6 * p + 5];
+          a_tot += a_rows[p]; i_tot += i_rows[p]; inA += recvA[p]; inI += recvI[p];
+        }
+        throw_if_any_failed(ctx, err, codes);  // from here on every rank has a plan and no failure so far
+        // the exact totals decide (the estimates only said whether counting ahead was worth it)
+        if (cross || (a_tot <= kSmallSideRows && a_tot <= i_tot)) {
+          A2 = run.allgather_rel(A, a_rows);
+          have_A2 = true;
+        } else if (i_tot <= kSmallSideRows) {
+          I2 = run.allgather_rel(I, i_rows);
+          have_I2 = true;
+          I_spread.clear();  // the result falls where the arm's rows are
         } else {
-          pa.new_src[pa.nnew++] = c;
-          new_cls.push_back(r.cls[c]);
+          // ---- redistribution by the join key
+          if (!all_counted) {  // the estimates were off (the same on every rank): count now, exchange the counts
+            run_local(err, [&] { count_destinations(false); });
+            std::vector<uint64_t> send2(3 * W), recv2(3 * W);
+            for (int p = 0; p < W; ++p) { send2[3 * p] = sendA[p]; send2[3 * p + 1] = sendI[p]; send2[3 * p + 2] = (uint64_t)(err ? -err.code : 0); }
+            comm_check(cm.exchange_host(cm.user, send2.data(), recv2.data(), 3), "exchange of shuffle counts");
+            ++run.n_host_exchanges;
+            inA = inI = 0;
+            for (int p = 0; p < W; ++p) { recvA[p] = recv2[3 * p]; recvI[p] = recv2[3 * p + 1]; codes[p] = -(int)recv2[3 * p + 2]; inA += recvA[p]; inI += recvI[p]; }
+            throw_if_any_failed(ctx, err, codes);
+          }
+          // Sizes every rank can check for every rank would need the whole matrix of counts; a rank whose own inbox
+          // is too large stops alone here, and its peers' next collective fails instead of waiting (documented limit).
+          if (inA >= (1ull << 32) || inI >= (1ull << 32)) throw DxError(DX_E_RANGE, "2^32 rows or more arrive on one GPU");
+          A2 = run.exchange_rel(A, destA.p, sendA, recvA);
+          have_A2 = true;
+          if (move_I) {
+            I2 = run.exchange_rel(I, destI.p, sendI, recvI);
+            have_I2 = true;
+            I_spread = key_cls;
+          }
         }
       }
-      if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
-      // both sides hash the key columns in the same order: ascending variable class
-      if (pa.nkey == 2 && key_cls[0] > key_cls[1]) {
-        std::swap(key_cls[0], key_cls[1]);
-        std::swap(pa.key_src[0], pa.key_src[1]);
-        std::swap(pa.key_col[0], pa.key_col[1]);
-      }
-      LocalRel A2 = shuffle(ctx, A, pa.nkey, pa.key_src);  // cross product: every rank gets the whole arm
-      A = LocalRel();
-      if (pa.nkey > 0 && I_spread != key_cls) {
-        LocalRel I2 = shuffle(ctx, I, pa.nkey, pa.key_col);
-        I = std::move(I2);
-        I_spread = key_cls;
-      }
-      // local join: I is the build side, the received arm rows are streamed
-      RelDev Id{};
-      Id.ncols = I.ncols;
-      Id.cap = (uint32_t)I.rows;
-      DevBuf<unsigned long long> i_count(pool, 1);
-      const unsigned long long i_rows = I.rows;
-      DX_HIP(hipMemcpyAsync(i_count.p, &i_rows, 8, hipMemcpyHostToDevice, s));
-      Id.count = i_count.p;
-      for (int c = 0; c < I.ncols; ++c) Id.col[c] = I.col[c];
-      pa.I = Id;
-      std::vector<DevBuf<uint32_t>> tmp32;
-      if (pa.nkey > 0) {
-        uint32_t hsize = 1024;
-        while (hsize < 2ull * I.rows && hsize < (1u << 31)) hsize <<= 1;
-        tmp32.emplace_back(pool, hsize);
-        uint32_t* heads = tmp32.back().p;
-        tmp32.emplace_back(pool, std::max<uint64_t>(I.rows, 1));
-        uint32_t* next = tmp32.back().p;
-        DX_HIP(hipMemsetAsync(heads, 0xFF, (size_t)hsize * 4, s));
-        BuildArgs ba{};
-        ba.I = Id; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
-        ba.heads = heads; ba.next = next; ba.hmask = hsize - 1;
-        if (I.rows) hipLaunchKernelGGL(k_build, dim3(scan_grid(I.rows)), dim3(256), 0, s, ba);
-        pa.heads = heads; pa.next = next; pa.hmask = hsize - 1;
-      }
-      ArmDev ad{};
-      ad.rows = (uint32_t)A2.rows;
-      ad.fs = ad.fo = -1;
-      ad.nsrc = r.ncols;
-      ad.direct = 1;
-      for (int c = 0; c < r.ncols; ++c) ad.d[c] = A2.col[c];
-      pa.arm = ad;
-      pa.count_only = count_only ? 1 : 0;
-      pa.out_count = counter.p;
-      LocalRel out;
-      out.ncols = I.ncols + pa.nnew;
-      uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(I.rows, A2.rows), 1);
-      for (int attempt = 0;; ++attempt) {
-        RelDev od{};
-        od.ncols = out.ncols;
-        od.count = counter.p;
-        if (!count_only) {
-          if (cap >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
-          out.own.clear();
-          for (int c = 0; c < out.ncols; ++c) { out.own.emplace_back(pool, cap); out.col[c] = out.own.back().p; od.col[c] = out.col[c]; }
-          od.cap = (uint32_t)cap;
+      if (!have_A2) { A2 = std::move(A); }
+      A = DevRel();
+      if (have_I2) I = std::move(I2);
+      // ---- local join: I is the build side, the arm's rows are streamed
+      DevRel out;
+      run_local(err, [&] {
+        RelDev Id{};
+        Id.ncols = I.ncols;
+        Id.cap = (uint32_t)I.rows;
+        Id.count = I.count.p;
+        for (int c = 0; c < I.ncols; ++c) Id.col[c] = I.col[c];
+        pa.I = Id;
+        std::vector<DevBuf<uint32_t>> tmp32;
+        if (pa.nkey > 0) {
+          uint32_t hsize = 1024;
+          while (hsize < 2ull * I.rows && hsize < (1u << 31)) hsize <<= 1;
+          tmp32.emplace_back(pool, hsize);
+          uint32_t* heads = tmp32.back().p;
+          tmp32.emplace_back(pool, std::max<uint64_t>(I.rows, 1));
+          uint32_t* next = tmp32.back().p;
+          DX_HIP(hipMemsetAsync(heads, 0xFF, (size_t)hsize * 4, s));
+          BuildArgs ba{};
+          ba.I = Id; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
+          ba.heads = heads; ba.next = next; ba.hmask = hsize - 1;
+          if (I.rows) hipLaunchKernelGGL(k_build, dim3(scan_grid(I.rows)), dim3(256), 0, s, ba);
+          pa.heads = heads; pa.next = next; pa.hmask = hsize - 1;
         }
-        pa.out = od;
-        DX_HIP(hipMemsetAsync(counter.p, 0, 8, s));
-        if (A2.rows) launch_probe(s, A2.rows, pa);
-        out.rows = read_counter();
-        if (count_only || out.rows <= cap) break;
-        if (attempt) throw DxError(DX_E_RANGE, "join output did not fit its exact size");
-        cap = out.rows;  // the counter holds the exact size: one more pass
-      }
-      local_count = out.rows;
-      explain << " -> " << out.rows << " rows here\n";
-      if (!count_only) {
+        ArmDev ad{};
+        ad.rows = (uint32_t)A2.rows;
+        ad.fs = ad.fo = -1;
+        ad.nsrc = r->ncols;
+        ad.direct = 1;
+        for (int c = 0; c < r->ncols; ++c) ad.d[c] = A2.col[c];
+        pa.arm = ad;
+        pa.count_only = count_only ? 1 : 0;
+        uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(I.rows, A2.rows), 1);
+        for (int attempt = 0;; ++attempt) {
+          if (count_only) { out = DevRel(); out.count = DevBuf<unsigned long long>(pool, 1); out.ncols = I.ncols + pa.nnew; }
+          else out = run.make_rel(I.ncols + pa.nnew, cap);
+          RelDev od{};
+          od.ncols = out.ncols;
+          od.count = out.count.p;
+          od.cap = count_only ? 0 : (uint32_t)out.cap;
+          for (int c = 0; c < out.ncols && !count_only; ++c) od.col[c] = out.col[c];
+          pa.out = od;
+          pa.out_count = out.count.p;
+          DX_HIP(hipMemsetAsync(out.count.p, 0, 8, s));
+          if (A2.rows) launch_probe(s, A2.rows, pa);
+          read_rows(out);
+          if (count_only || out.rows <= cap) break;
+          if (attempt) throw DxError(DX_E_RANGE, "join output did not fit its exact size");
+          cap = out.rows;  // the counter holds the exact size: one more pass
+        }
+        local_count = out.rows;
+        explain << " -> " << out.rows << " rows here\n";
+      });
+      if (!count_only && !err) {
         I = std::move(out);
         for (int c : new_cls) I_cls.push_back(c);
       }
     }
-    uint64_t total = local_count;
-    comm_check(cm.allreduce_sum(cm.user, &total, 1), "allreduce_sum");
+    // ---- the count over all ranks, and the last chance for a rank to report a failure
+    uint64_t fin[1 + kErrSlots] = {0};
+    fin[0] = err ? 0 : local_count;
+    if (err) fin[1 + err_slot(err.code)] = 1;
+    comm_check(cm.allreduce_sum(cm.user, fin, 1 + kErrSlots), "allreduce_sum");
+    {
+      std::vector<int> codes;  // by slot rather than by rank: the sum says which kinds of failure occurred
+      for (int sl = 0; sl < kErrSlots; ++sl)
+        if (fin[1 + sl]) codes.push_back(err_code_of_slot(sl));
+      throw_if_any_failed(ctx, err, codes);
+    }
+    res->names = plan.select_names;
+    res->virtual_terms = plan.virtual_terms;
     res->count = local_count;
-    res->global_count = total;
+    res->global_count = fin[0];
     if (mode == DX_QUERY_BINDINGS) {
       res->has_bindings = true;
       for (size_t c = 0; c < plan.select_cls.size(); ++c) {
         int at = -1;
         for (size_t j = 0; j < I_cls.size(); ++j)
           if (I_cls[j] == plan.select_cls[c]) at = (int)j;
-        if (at < 0) throw DxError(DX_E_MALFORMED, "SQL: selected column is not produced by any sub-select");
+        if (at < 0) throw DxError(DX_E_MALFORMED, "SQL: selected column is not produced by any sub-select");  // the same on every rank
         DevBuf<int64_t> col(pool, std::max<uint64_t>(res->count, 1));
         if (res->count) DX_HIP(hipMemcpyAsync(col.p, I.col[at], res->count * 8, hipMemcpyDeviceToDevice, s));
         res->cols.push_back(std::move(col));
       }
       DX_HIP(hipStreamSynchronize(s));
     }
+    explain << "collectives: " << run.n_host_exchanges << " host exchanges, " << run.n_data_collectives << " data, 1 sum\n";
     res->plan = explain.str();
     return res;
   } catch (...) {

@@ -239,10 +239,10 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   const uint64_t* keys = ps.uniq.p;
   uint64_t n_keys = ps.n_uniq_slots;
   if (cm.world > 1) {
-    if (!cm.allgather || !cm.exchange_counts) throw DxError(DX_E_INVAL, "the communicator lacks the collectives of the measures");
+    if (!cm.allgather || !cm.exchange_host) throw DxError(DX_E_INVAL, "the communicator lacks the collectives of the measures");
     if (!ps.local_keys.p && ps.n_local_keys) throw DxError(DX_E_INVAL, "the partition run was not made with this communicator");
     std::vector<uint64_t> mine(cm.world, ps.n_local_keys), counts(cm.world, 0);
-    if (cm.exchange_counts(cm.user, mine.data(), counts.data())) throw DxError(DX_E_IO, "collective failed: exchange_counts");
+    if (cm.exchange_host(cm.user, mine.data(), counts.data(), 1)) throw DxError(DX_E_IO, "collective failed: exchange_host");
     n_keys = 0;
     for (uint64_t c : counts) n_keys += c;
     gathered = DevBuf<uint64_t>(pool, n_keys);

@@ -111,6 +111,8 @@ struct CatalogTable {
 
 }  // namespace dx
 
+namespace dx { struct RcclComm; }
+
 struct dx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -135,7 +137,8 @@ struct dx_ctx {
   void* noalloc_scratch = nullptr;
   size_t noalloc_scratch_bytes = 0;
   // several GPUs: collectives handed in by the host; world == 1 means single-GPU execution
-  dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  dx_comm comm{0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  dx::RcclComm* native_comm = nullptr;  // the communicator made by dx_comm_rccl_init (comm.user points at it)
 };
 
 namespace dx {
@@ -229,4 +232,61 @@ void* noalloc_scratch_of_current_device(size_t* bytes);     // the device array 
 uint64_t run_query_count_noalloc(dx_ctx* ctx, const std::string& sql);
 dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode);
 extern const char* const kStageNames[12];
+// dx_comm_rccl.cpp
+void rccl_unique_id(unsigned char* out);
+void rccl_comm_create(dx_ctx* ctx, const unsigned char* id_bytes, int rank, int world);
+void rccl_comm_destroy(dx_ctx* ctx);
+void rccl_rendezvous_file(const char* path, int rank, int timeout_ms, unsigned char* id);
+const char* rccl_comm_last_error(dx_ctx* ctx);
+
+// ---- agreement between ranks ---------------------------------------------------------------------------
+// A rank that fails between two collectives must not simply return: its peers would wait for it in the next
+// one for ever. Every rank therefore brings the outcome of its local work to the next collective, and all
+// of them leave with the same error code when any of them failed.
+constexpr int kErrSlots = 8;
+inline int err_slot(int code) {
+  switch (code) {
+    case DX_E_NOENT: return 0;
+    case DX_E_IO: return 1;
+    case DX_E_NOMEM: return 2;
+    case DX_E_INVAL: return 3;
+    case DX_E_RANGE: return 4;
+    case DX_E_MALFORMED: return 5;
+    case DX_E_UNSUPPORTED: return 6;
+    default: return 7;
+  }
+}
+inline int err_code_of_slot(int slot) {
+  static const int codes[kErrSlots] = {DX_E_NOENT, DX_E_IO, DX_E_NOMEM, DX_E_INVAL, DX_E_RANGE, DX_E_MALFORMED, DX_E_UNSUPPORTED, DX_E_HIP};
+  return codes[slot];
+}
+// An error every rank of the group leaves with (thrown by the two functions below): it must not be brought to
+// another agreement.
+struct AgreedError : DxError {
+  AgreedError(int c, const std::string& m) : DxError(c, m) {}
+};
+struct LocalError {
+  int code = 0;
+  std::string msg;
+  explicit operator bool() const { return code != 0; }
+};
+// Runs f unless an earlier step of this rank has already failed; a failure is kept, not thrown.
+template <typename F>
+void run_local(LocalError& err, F&& f) {
+  if (err) return;
+  try {
+    f();
+  } catch (const DxError& e) {
+    err.code = e.code; err.msg = e.what();
+  } catch (const HipError& e) {
+    err.code = DX_E_HIP; err.msg = e.what();
+  } catch (const std::bad_alloc&) {
+    err.code = DX_E_NOMEM; err.msg = "host allocation failed";
+  }
+}
+// Collective: every rank passes its own outcome; if any rank failed, all of them throw the error of the lowest
+// failing slot (a rank that did not fail itself reports which error its peers had).
+void agree_or_throw(dx_ctx* ctx, const LocalError& err);
+// The same decision from codes that have already been exchanged (one per rank; 0 = fine).
+void throw_if_any_failed(dx_ctx* ctx, const LocalError& mine, const std::vector<int>& codes_by_rank);
 }  // namespace dx

@@ -33,7 +33,8 @@ EXPORTS = [
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
     "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
-    "dx_query_count_noalloc",
+    "dx_query_count_noalloc", "dx_rccl_unique_id", "dx_comm_rccl_init", "dx_comm_rccl_init_file", "dx_comm_selftest",
+    "dx_load_tables_sharded",
 ]
 
 
@@ -127,6 +128,11 @@ def load_library():
         "dx_dictionary_load": (c_int, [c_void_p, c_void_p, u64p, c_uint64]),
         "dx_load_table_ids": (c_int, [c_void_p, c_char_p, i64p, i64p, c_uint64]),
         "dx_set_comm": (c_int, [c_void_p, c_void_p]),
+        "dx_rccl_unique_id": (c_int, [c_void_p]),
+        "dx_comm_rccl_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+        "dx_comm_rccl_init_file": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int]),
+        "dx_comm_selftest": (c_int, [c_void_p]),
+        "dx_load_tables_sharded": (c_int, [c_void_p, POINTER(c_char_p), c_int, u64p]),
         "dx_declare_remote_table": (c_int, [c_void_p, c_char_p]),
         "dx_table_stats": (c_int, [c_void_p, c_char_p, u64p]),
         "dx_set_table_stats": (c_int, [c_void_p, c_char_p, u64p]),
@@ -393,6 +399,37 @@ class Engine:
         """comm: an object with a `struct` attribute holding a dx_comm (opus_amd.host.comm.TorchComm), or None."""
         self._comm = comm  # keeps the callbacks alive
         self._check(self.lib.dx_set_comm(self.ctx, ctypes.byref(comm.struct) if comm is not None else None))
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """128 bytes that rank 0 hands to the other ranks before they all call comm_rccl_init."""
+        buf = ctypes.create_string_buffer(128)
+        rc = load_library().dx_rccl_unique_id(buf)
+        if rc != 0:
+            raise DxError(rc, "dx_rccl_unique_id failed (is librccl.so.1 loadable?)")
+        return buf.raw
+
+    def comm_rccl_init(self, unique_id: bytes, rank: int, world: int):
+        """Joins the group of `world` ranks over RCCL (collective: returns when all ranks have called it)."""
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id has 128 bytes")
+        self._comm = None
+        self._check(self.lib.dx_comm_rccl_init(self.ctx, ctypes.create_string_buffer(unique_id, 128), rank, world))
+
+    def comm_rccl_init_file(self, path: str, rank: int, world: int, timeout_ms: int = 60000):
+        self._comm = None
+        self._check(self.lib.dx_comm_rccl_init_file(self.ctx, path.encode(), rank, world, timeout_ms))
+
+    def comm_selftest(self):
+        self._check(self.lib.dx_comm_selftest(self.ctx))
+
+    def load_tables_sharded(self, keys) -> int:
+        """Collective preloadTables: partition q's tables on rank q % world, statistics shared; rows over all ranks."""
+        keys = [k.encode() for k in keys]
+        arr = (c_char_p * len(keys))(*keys)
+        rows = c_uint64(0)
+        self._check(self.lib.dx_load_tables_sharded(self.ctx, arr, len(keys), byref(rows)))
+        return rows.value
 
     def declare_remote_table(self, key: str):
         self._check(self.lib.dx_declare_remote_table(self.ctx, key.encode()))

@@ -13,7 +13,7 @@ from ctypes import CFUNCTYPE, POINTER, c_int, c_uint64, c_void_p
 
 import numpy as np
 
-COUNTS_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), POINTER(c_uint64))
+COUNTS_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int)
 EXCHANGE_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, POINTER(c_uint64), c_void_p, POINTER(c_uint64), c_int)
 ALLREDUCE_FN = CFUNCTYPE(c_int, c_void_p, POINTER(c_uint64), c_int)
 ALLGATHER_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_void_p, POINTER(c_uint64), c_int)
@@ -21,9 +21,9 @@ ALLREDUCE_DEV_FN = CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_int)
 
 
 class DxComm(ctypes.Structure):
-    _fields_ = [("rank", c_int), ("world", c_int), ("user", c_void_p), ("exchange_counts", COUNTS_FN),
+    _fields_ = [("rank", c_int), ("world", c_int), ("user", c_void_p), ("exchange_host", COUNTS_FN),
                 ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN), ("allgather", ALLGATHER_FN),
-                ("allreduce_sum_dev", ALLREDUCE_DEV_FN)]
+                ("allreduce_sum_dev", ALLREDUCE_DEV_FN), ("stream_ordered", c_int)]
 
 
 class _DevicePointer:
@@ -70,7 +70,8 @@ class TorchComm:
         self.on_device = dist.get_backend(group) == "nccl"
         self._fns = (COUNTS_FN(self._counts), EXCHANGE_FN(self._exchange), ALLREDUCE_FN(self._allreduce),
                      ALLGATHER_FN(self._allgather), ALLREDUCE_DEV_FN(self._allreduce_dev))
-        self.struct = DxComm(self.rank, self.world, None, *self._fns)
+        # stream_ordered = 0: torch works on its own streams, so every callback returns when its result is complete
+        self.struct = DxComm(self.rank, self.world, None, *self._fns, 0)
 
     # every callback returns 0, or 1 after printing the exception: the library turns that into DX_E_IO
     def _guard(self, fn):
@@ -81,16 +82,18 @@ class TorchComm:
             traceback.print_exc(file=sys.stderr)
             return 1
 
-    def _counts(self, user, send, recv):
+    def _counts(self, user, send, recv, n):
+        """exchange_host: `world` groups of n words each way; group p of recv = what peer p sent at position `rank`."""
         def run():
             import torch
-            mine = torch.tensor([int(send[p]) for p in range(self.world)], dtype=torch.int64)
+            words = n * self.world
+            mine = torch.from_numpy(np.ctypeslib.as_array(send, shape=(words,)).astype(np.int64))
             if self.on_device:
                 mine = mine.cuda()
-            everyone = [torch.empty_like(mine) for _ in range(self.world)]
-            self.dist.all_gather(everyone, mine, group=self.group)
-            for p in range(self.world):
-                recv[p] = int(everyone[p][self.rank])
+            everyone = torch.empty(self.world * words, dtype=torch.int64, device=mine.device)
+            self.dist.all_gather_into_tensor(everyone, mine, group=self.group)
+            got = everyone.view(self.world, self.world, n)[:, self.rank, :].contiguous().cpu().numpy()
+            np.ctypeslib.as_array(recv, shape=(words,))[:] = got.reshape(-1).astype(np.uint64)
         return self._guard(run)
 
     def _exchange(self, user, send_dev, send_counts, recv_dev, recv_counts, elem_bytes):
@@ -129,12 +132,12 @@ class TorchComm:
     def _allreduce(self, user, values, n):
         def run():
             import torch
-            t = torch.tensor([int(values[i]) for i in range(n)], dtype=torch.int64)
+            view = np.ctypeslib.as_array(values, shape=(n,))
+            t = torch.from_numpy(view.astype(np.int64))
             if self.on_device:
                 t = t.cuda()
             self.dist.all_reduce(t, group=self.group)
-            for i in range(n):
-                values[i] = int(t[i])
+            view[:] = t.cpu().numpy().astype(np.uint64)
         return self._guard(run)
 
 

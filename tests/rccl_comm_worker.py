@@ -23,7 +23,7 @@ def main(out_path):
 
     send = (u64 * 1)(7)
     recv = (u64 * 1)(0)
-    res["counts_rc"] = c.exchange_counts(None, send, recv)
+    res["counts_rc"] = c.exchange_host(None, send, recv, 1)
     res["counts"] = int(recv[0])
 
     for name, dtype, eb in (("i64", torch.int64, 8), ("i32", torch.int32, 4), ("u8x12", torch.uint8, 12)):
@@ -51,6 +51,26 @@ def main(out_path):
         want = t.clone()
         rc = c.allreduce_sum_dev(None, t.data_ptr(), 300, eb)
         res["allreduce_dev_" + name] = [rc, bool(torch.equal(t, want))]
+
+    # the same collectives through the engine's self-test, over the torch communicator ...
+    from opus_amd.engine import Engine
+    e = Engine(0)
+    e.set_comm(comm)
+    e.comm_selftest()
+    res["selftest_torch"] = True
+    # ... and over the communicator the library makes itself on librccl (a group of one rank: RCCL admits one rank
+    # per GPU), formed once from a unique id handed over in memory and once through the rendezvous file
+    e.comm_rccl_init(Engine.rccl_unique_id(), 0, 1)
+    e.comm_selftest()
+    res["selftest_native"] = True
+    e.comm_rccl_init_file(out_path + ".rccl_id", 0, 1)
+    e.comm_selftest()
+    res["selftest_native_file"] = True
+    # with a group of one rank the engine works as on a single GPU
+    st = e.partition_text(b"<a> <p> <b> .\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <C> .\n", "<C>\t0", 1)
+    res["partition_rows"] = int(st.n_rows)
+    e.set_comm(None)   # leaves the group
+    e.close()
 
     dist.barrier()
     dist.destroy_process_group()

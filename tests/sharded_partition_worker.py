@@ -50,7 +50,7 @@ def main(out_path):
         return {"cc": sorted([list(k), list(v)] for k, v in m["schema_cc"].items()), "freq": sorted(m["schema_node_freq"].items()),
                 "count": sorted(m["schema_node_count"].items())}
     share = {"rank": rank, "measures": jsonable(meas), "n_terms": int(st.n_terms), "n_unique": int(st.n_unique), "n_edges": int(st.n_edges),
-             "n_vertices": int(st.n_vertices), "n_triples_in": int(st.n_triples),
+             "n_vertices": int(st.n_vertices), "n_triples_in": int(st.n_triples), "n_vp_index": int(st.n_vp_index),
              "parts": [sorted(p) for p in art["parts"]], "node_index": sorted(art["node_index"]),
              "vp": sorted(("%s/%s" % k, sorted(v)) for k, v in art["vp"].items()),
              "vp_index": {k: sorted((u, sorted(v)) for u, v in d.items()) for k, d in art["vp_index"].items()},
@@ -65,7 +65,7 @@ def main(out_path):
         e1 = Engine(0)
         st1 = e1.partition_text(arr, ci, n_parts)
         a1 = engine_artifacts(e1)
-        alone = {"measures": jsonable(a1), "n_terms": int(st1.n_terms), "n_unique": int(st1.n_unique), "n_edges": int(st1.n_edges), "n_vertices": int(st1.n_vertices),
+        alone = {"measures": jsonable(a1), "n_terms": int(st1.n_terms), "n_unique": int(st1.n_unique), "n_edges": int(st1.n_edges), "n_vertices": int(st1.n_vertices), "n_vp_index": int(st1.n_vp_index),
                  "parts": [sorted(p) for p in a1["parts"]], "node_index": sorted(a1["node_index"]),
                  "vp": sorted(("%s/%s" % k, sorted(v)) for k, v in a1["vp"].items()),
                  "vp_index": {k: sorted((u, sorted(v)) for u, v in d.items()) for k, d in a1["vp_index"].items()}}
@@ -98,9 +98,22 @@ def main(out_path):
         dist.all_gather_object(got, rows)
         queries[name] = {"count": rb.count, "want_count": want_count, "columns": cols, "want_columns": want_cols,
                          "rows": sorted([list(r) for sh in got for r in sh]), "want_rows": want_rows}
+    # a malformed line in one rank's part of the text: every rank returns DX_E_MALFORMED, nobody waits for ever
+    from opus_amd.engine import DxError
+    bad = np.concatenate([mine, np.frombuffer(b"<only-two> <fields>\n", dtype=np.uint8)]) if rank == 1 else mine
+    try:
+        e.partition_text(bad, ci, n_parts)
+        code = 0
+    except DxError as ex:
+        code = ex.code
+    codes = [None] * world
+    dist.all_gather_object(codes, code)
+    # and the group partitions again afterwards
+    st2 = e.partition_text(mine, ci, n_parts)
+    assert int(st2.n_terms) == int(st.n_terms)
     if rank == 0:
         with open(out_path, "w") as f:
-            json.dump({"shares": shares, "alone": alone, "queries": queries, "n_triples": int(n_triples)}, f)
+            json.dump({"shares": shares, "alone": alone, "queries": queries, "n_triples": int(n_triples), "malformed": codes}, f)
     e.close()
     dist.destroy_process_group()
 

@@ -54,11 +54,19 @@ def main(out_path):
     comm = TorchComm()
     owner = lambda q: shard.partition_owner(q, world)  # noqa: E731
     results = {}
-    for name, (sql, parts) in statements.items():
+    # every statement twice: with the default rule (at this size every join sends its small side to all ranks) and with
+    # every join redistributing both sides by the join key
+    runs = [(name, st, None) for name, st in statements.items()] + [(name + "#hashed", st, "0") for name, st in statements.items()]
+    for name, (sql, parts), small_side in runs:
+        if small_side is None:
+            os.environ.pop("DX_SMALL_SIDE_ROWS", None)
+        else:
+            os.environ["DX_SMALL_SIDE_ROWS"] = small_side
         # together
         e.set_comm(comm)
         e.unload_all()
-        loaded = load_tables_sharded(e, comm, parts, owner)
+        # the library's own collective preloadTables on every other statement, the host-side variant on the rest
+        loaded = e.load_tables_sharded(parts) if len(results) % 2 == 0 else load_tables_sharded(e, comm, parts, owner)
         rc = e.query(sql, DX_QUERY_COUNT)
         rb = e.query(sql, DX_QUERY_BINDINGS)
         rows, cols = rb.rows()
@@ -77,7 +85,40 @@ def main(out_path):
             entry["alone"] = {"count": ra.count, "columns": acols, "rows": [tuple(r) for r in arows], "loaded": alone_loaded}
         results[name] = entry
         dist.barrier()
+    # ---- a rank that fails must not strand its peer: both return the same error
+    from opus_amd.engine import DxError
+    failures = {}
+    os.environ.pop("DX_SMALL_SIDE_ROWS", None)
+    e.set_comm(comm)
+    e.comm_selftest()
+    sql, parts = statements["Q2.txt"]
+    e.unload_all()
+    e.load_tables_sharded(parts)
+    if rank == 1:   # this rank forgets one table of the statement: its planner fails, the other's does not
+        e.unload_all()
+        for p in parts[1:]:
+            (e.load_table if owner(int(p.split("-")[0])) == rank else e.declare_remote_table)(p)
+    try:
+        e.query(sql, DX_QUERY_COUNT)
+        failures["missing_table"] = 0
+    except DxError as ex:
+        failures["missing_table"] = ex.code
+    # a table whose files do not exist on its owner: the collective load fails on every rank
+    try:
+        e.unload_all()
+        e.load_tables_sharded(["00001-_3=_no_such_predicate_", "00000-_3=_no_such_predicate_"])
+        failures["missing_file"] = 0
+    except DxError as ex:
+        failures["missing_file"] = ex.code
+    # and the group still works afterwards
+    e.unload_all()
+    e.load_tables_sharded(parts)
+    failures["after"] = e.query(sql, DX_QUERY_COUNT).count
+    failures["want_after"] = results["Q2.txt"]["count"]
+    all_f = [None] * world
+    dist.all_gather_object(all_f, failures)
     if rank == 0:
+        results["__failures__"] = all_f
         with open(out_path, "w") as f:
             json.dump(results, f)
     e.close()

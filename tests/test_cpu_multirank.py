@@ -72,9 +72,15 @@ def _comm_worker(rank, world, port, out):
         # the library calls these through the C function pointers: do the same
         send = (ctypes.c_uint64 * world)(*[100 * rank + p for p in range(world)])
         recv = (ctypes.c_uint64 * world)()
-        assert st.exchange_counts(None, send, recv) == 0
+        assert st.exchange_host(None, send, recv, 1) == 0
+        # three words per peer: group p of recv is what peer p sent at position `rank`
+        send3 = (ctypes.c_uint64 * (3 * world))(*[1000 * rank + 10 * p + k for p in range(world) for k in range(3)])
+        recv3 = (ctypes.c_uint64 * (3 * world))()
+        assert st.exchange_host(None, send3, recv3, 3) == 0
+        assert list(recv3) == [1000 * p + 10 * rank + k for p in range(world) for k in range(3)]
         vals = (ctypes.c_uint64 * 2)(rank + 1, 10)
         assert st.allreduce_sum(None, vals, 2) == 0
+        assert st.stream_ordered == 0
         out.put((rank, list(recv), list(vals), st.rank, st.world))
     finally:
         dist.destroy_process_group()
@@ -111,7 +117,7 @@ def _collectives_worker(rank, world, port, out):
         sc = [rank + 1, 2]
         send = np.arange(sum(sc), dtype=np.int64) + 100 * rank
         rc_c = u64([0] * world)
-        assert st.exchange_counts(None, u64(sc), rc_c) == 0
+        assert st.exchange_host(None, u64(sc), rc_c, 1) == 0
         rc = list(rc_c)
         recv = np.full(sum(rc), -1, dtype=np.int64)
         assert st.exchange(None, ptr(send), u64(sc), ptr(recv), u64(rc), 8) == 0

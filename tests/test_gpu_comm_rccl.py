@@ -32,3 +32,5 @@ def test_callbacks_over_rccl_single_rank(tmp_path):
         assert r[k] == [0, True], k
     assert r["exchange_empty_rc"] == 0
     assert r["allreduce_rc"] == 0 and r["allreduce"] == [5, 11]
+    assert r["selftest_torch"] and r["selftest_native"] and r["selftest_native_file"]
+    assert r["partition_rows"] == 2

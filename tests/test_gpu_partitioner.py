@@ -115,6 +115,24 @@ def test_malformed_lines_are_errors(engine, text):
     assert ei.value.code == -74
 
 
+def test_directory_name_of_a_predicate_with_a_supplementary_character(engine):
+    """uriToStorage is replaceAll("[^A-Za-z0-9]", "_") (DAP.scala:512-514): java.util.regex matches by code point,
+    so a character outside the BMP becomes one '_', not one per UTF-16 unit. The table must be loadable under the
+    key the translator derives from the predicate's text."""
+    from oracle import dap_oracle
+    pred = "<http://x/p\U00010400q\u00e9>"
+    text = "<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> %s <b> .\n<b> %s <c> .\n" % (pred, pred)
+    _, got, ref = _run(engine, text, "<A>\t0\n", 1)
+    name = dap_oracle.uri_to_storage(pred)
+    assert name == "_http___x_p_q__"
+    key = "00000-_3=" + name
+    assert ("00000", "_3=" + name) in ref["vp"]
+    engine.unload_all()
+    assert engine.load_table(key) == 1   # (a, b): b has no type, so (b, c) is placed nowhere
+    view = "table" + key.replace("-", "_").replace("=", "_E_")
+    assert engine.query("SELECT tab0.X AS X FROM (SELECT s AS X FROM %s) AS tab0 " % view).count == 1
+
+
 def test_class_index_partition_out_of_range(engine):
     from opus_amd.engine import DxError
     with pytest.raises(DxError) as ei:
