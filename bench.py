@@ -425,24 +425,21 @@ def main():
         stage_names = [eng.lib.dx_part_stage_name(i).decode() for i in range(12)]
         stage_avg = {stage_names[i]: float(np.mean([s[i] for s in stage_ms])) for i in range(12) if stage_names[i]}
         # Dominant kernel of the step = the longest of the kernels the library times on its own stream with
-        # a hipEvent pair each (tokenise+hash, dictionary insert, dictionary verify). Algorithmic bytes per
-        # launch: what the kernel has to read and write once.
+        # a hipEvent pair each (tokenise, table clear, slot claims). Algorithmic bytes per launch: what the
+        # kernel has to read and write once.
         n_rec, n_occ = st.n_triples, 3 * st.n_triples
-        import ctypes
-        pool_bytes = ctypes.c_uint64(0)                          # every distinct term once
-        all_ids = np.arange(st.n_terms, dtype=np.int64)
-        eng._check(eng.lib.dx_terms_bytes(eng.ctx, all_ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), all_ids.size,
-                                          ctypes.byref(pool_bytes)))
+        n_ent = int(st.n_dict_entries)                          # occurrences left after the folding inside the tiles
         kernels = {
-            # one pass over the text: the text itself, per record three spans (24 B), three slot indices (12 B) and
-            # the kind (1 B) written, per occurrence its 16-byte dictionary slot read, and every distinct term's
-            # first occurrence read once more for the byte comparisons
-            "k_tokenise (text -> term spans, hashes, dictionary slots, byte comparison of repeated terms)":
-                (stage_avg["tokenise_hash"], n_bytes + (37 + 48) * n_rec + pool_bytes.value),
+            # one pass over the text: the text itself and its 2-byte record-start mask per 16 bytes read; per record the
+            # three occurrences' entry numbers (12 B) and the kind (1 B) written; per dictionary entry its span and
+            # its hash (16 B) written
+            "k_tokenise (text -> term spans, hashes, terms of a tile folded onto their first occurrence there)":
+                (stage_avg["tokenise_hash"], n_bytes + n_bytes // 8 + 13 * n_rec + 16 * n_ent),
             "k_ht_clear (16-byte slots)":
-                (stage_avg["dict_clear_kernel"], 16 * (1 << max(10, math.ceil(math.log2(max(1.5 * n_rec, 1)))))),
-            "k_dict_first (is this occurrence its term's first)":
-                (stage_avg["dict_first_kernel"], 29 * n_occ),
+                (stage_avg["dict_clear_kernel"], 16 * (1 << max(10, math.ceil(math.log2(max(n_rec // 2, 1)))))),
+            # per entry: span and hash read (16 B), its 16-byte slot read, the slot's number written (4 B)
+            "k_entry_claim (dictionary slots of the tiles' entries)":
+                (stage_avg["dict_claim_kernel"], 36 * n_ent),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
@@ -451,7 +448,7 @@ def main():
         # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; see profiles/summarise.py); null when the
         # workload is not the profiled one
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc_path) and total_univ == 100 and world == 1 and args.partitions == 8:
             pmc = json.load(open(pmc_path))
             names = [w for w in dom.replace("+", " ").split() if w.startswith("k_")]
@@ -482,6 +479,7 @@ def main():
             "partition_stage_ms": stage_avg,
             "partition_algorithmic_GBps": hp1_alg_bytes / med(part_s) / 1e9,
             "replication_factor": R,
+            "dictionary_entries": n_ent,
             "query_geomean_ms": geo,
             "query_geomean_device_ms": geo_dev,
             "query_ms": q_med,

@@ -55,7 +55,7 @@ typedef struct dx_part_stats {
   uint32_t n_predicates;
   uint32_t n_tables;        /* non-empty (partition, predicate) vertical-partition tables */
   uint32_t hash_retries;    /* dictionary rebuilds caused by a true 64-bit hash collision */
-  uint32_t reserved;
+  uint32_t n_dict_entries;  /* occurrences that went to the dictionary table: the rest equalled an earlier one of their 32 KiB tile */
   double ms_total;          /* device time of the whole call, inputs already in HBM */
   double ms_stage[12];      /* see dx_part_stage_name() */
 } dx_part_stats;

@@ -252,15 +252,18 @@ __device__ __noinline__ void tokenise_record_slow(const uint8_t* __restrict__ te
   out.kind = kd;
 }
 
-// Fast path: one block stages a 32 KiB tile (+ 2 KiB so that lines starting near its end are whole)
+// Fast path: one block stages a 32 KiB tile (+ 1 KiB so that lines starting near its end are whole)
 // into LDS with coalesced 16-byte loads, finds the record starts there, and each thread tokenises
-// records out of LDS four bytes at a time (unaligned words via v_alignbyte, delimiter search by SWAR,
-// hashing fused into the scan of subject and predicate).
+// one record out of LDS four bytes at a time (unaligned words via v_alignbyte, delimiter search by SWAR,
+// hashing fused into the scan of subject and predicate). The window, the start list and the tables of the
+// tile-level term folding below add up to just under 40 KiB, so that four blocks share a CU's 160 KiB.
 constexpr int TK_THREADS = 256;
-constexpr int TK_OVER = 2048;
+constexpr int TK_OVER = 1024;
 constexpr int TK_WIN = LS_TILE + TK_OVER;      // bytes staged per block
 constexpr int TK_PRE = 16;                     // bytes staged before the tile (only the last one is looked at)
-constexpr int TK_STARTS = 1024;                // record starts listed per round (a tile of ordinary lines has ~200)
+constexpr int TK_ROUND = TK_THREADS;           // records per round, one per thread (a tile of ordinary lines has ~200)
+constexpr int TK_BUCKETS = 768;                // direct-mapped table of the round's terms
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;     // the occurrence of a malformed record: it has no dictionary entry
 
 __device__ __forceinline__ uint32_t lds_word(const uint32_t* win, uint32_t pos) {  // 4 bytes at any byte offset
   const uint32_t i = pos >> 2;
@@ -311,7 +314,7 @@ __device__ __forceinline__ uint32_t scan_token(const uint32_t* win, uint32_t pos
 }
 
 // ---- dictionary slot claim, shared by the fused tokeniser and the entry-level build -----------------------
-constexpr uint32_t kMaxProbes = 1u << 14;  // a longer chain means the table is too full: the build restarts larger
+constexpr uint32_t kMaxProbes = 1u << 10;  // a longer chain means the table is too full: the build restarts larger
 constexpr uint64_t kNoHolder = ~0ull;      // k_ht_clear's representative word: nobody has claimed the slot's term yet
 
 __device__ __forceinline__ uint64_t diff_global(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t len) {
@@ -325,62 +328,45 @@ __device__ __forceinline__ uint64_t diff_global(const uint8_t* __restrict__ a, c
   for (; j < len; ++j) diff |= (uint64_t)(a[j] ^ b[j]);
   return diff;
 }
-
-// len bytes at window offset pos (LDS) against len bytes at b (global). The global side is requested 64 bytes at
-// a time as four independent 16-byte loads (one round trip instead of four: the loop is bound by memory
-// latency); chunks past the end are pulled back to the last 16 bytes, which compares some bytes twice and
-// never reads outside the term.
-__device__ __forceinline__ uint32_t lds_chunk_diff(const uint32_t* win, uint32_t at, const uint4& y) {
-  const uint32_t i = at >> 2, sh = at & 3;
-  const uint32_t w0 = win[i], w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
-  return (__builtin_amdgcn_alignbyte(w1, w0, sh) ^ y.x) | (__builtin_amdgcn_alignbyte(w2, w1, sh) ^ y.y) |
-         (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ y.z) | (__builtin_amdgcn_alignbyte(w4, w3, sh) ^ y.w);
-}
-__device__ __forceinline__ uint32_t diff_lds_global(const uint32_t* win, uint32_t pos, uint32_t len, const uint8_t* __restrict__ b) {
+// The same for two terms somewhere in the text, 64 bytes of each side requested at a time as four independent
+// 16-byte loads (one round trip instead of eight: the loop is bound by memory latency); chunks past the end are
+// pulled back to the last 16 bytes, which compares some bytes twice and never reads outside the terms.
+__device__ __forceinline__ uint32_t diff_global_wide(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t len) {
+  if (len < 16) return diff_global(a, b, len) != 0;
   uint32_t diff = 0;
-  if (len >= 16) {
-    const uint32_t last = len - 16;
-    for (uint32_t j = 0; j < len; j += 64) {
-      uint32_t off[4];
-      uint4 y[4];
+  const uint32_t last = len - 16;
+  for (uint32_t j = 0; j < len; j += 64) {
+    uint4 x[4], y[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        off[c] = j + 16 * c < last ? j + 16 * c : last;
-        __builtin_memcpy(&y[c], b + off[c], 16);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) diff |= lds_chunk_diff(win, pos + off[c], y[c]);
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t off = j + 16 * c < last ? j + 16 * c : last;
+      __builtin_memcpy(&x[c], a + off, 16);
+      __builtin_memcpy(&y[c], b + off, 16);
     }
-    return diff;
-  }
-  uint32_t i = pos >> 2;
-  const uint32_t sh = pos & 3;
-  uint32_t lo = win[i];
-  uint32_t j = 0;
-  for (; j + 4 <= len; j += 4) {
-    uint32_t y;
-    __builtin_memcpy(&y, b + j, 4);
-    const uint32_t w1 = win[i + 1];
-    diff |= __builtin_amdgcn_alignbyte(w1, lo, sh) ^ y;
-    lo = w1;
-    ++i;
-  }
-  if (j < len) {
-    const uint32_t x = __builtin_amdgcn_alignbyte(win[i + 1], lo, sh);
-    uint32_t y = 0;
-    for (uint32_t t = 0; j + t < len; ++t) y |= (uint32_t)b[j + t] << (8 * t);
-    diff |= (x ^ y) & ((1u << (8 * (len - j))) - 1u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) diff |= (x[c].x ^ y[c].x) | (x[c].y ^ y[c].y) | (x[c].z ^ y[c].z) | (x[c].w ^ y[c].w);
   }
   return diff;
 }
 
-// len bytes at window offset pa against len bytes at window offset pb, both in LDS (two occurrences of one tile)
+// len bytes at window offset pa against len bytes at window offset pb, both in LDS (two occurrences of one tile).
+// Four words of each side are requested per round: the loop is bound by LDS latency.
 __device__ __forceinline__ uint32_t diff_lds_lds(const uint32_t* win, uint32_t pa, uint32_t pb, uint32_t len) {
   uint32_t diff = 0;
   uint32_t ia = pa >> 2, ib = pb >> 2;
   const uint32_t sa = pa & 3, sb = pb & 3;
   uint32_t la = win[ia], lb = win[ib];
   uint32_t j = 0;
+  for (; j + 16 <= len; j += 16, ia += 4, ib += 4) {
+    const uint32_t a1 = win[ia + 1], a2 = win[ia + 2], a3 = win[ia + 3], a4 = win[ia + 4];
+    const uint32_t b1 = win[ib + 1], b2 = win[ib + 2], b3 = win[ib + 3], b4 = win[ib + 4];
+    diff |= (__builtin_amdgcn_alignbyte(a1, la, sa) ^ __builtin_amdgcn_alignbyte(b1, lb, sb)) |
+            (__builtin_amdgcn_alignbyte(a2, a1, sa) ^ __builtin_amdgcn_alignbyte(b2, b1, sb)) |
+            (__builtin_amdgcn_alignbyte(a3, a2, sa) ^ __builtin_amdgcn_alignbyte(b3, b2, sb)) |
+            (__builtin_amdgcn_alignbyte(a4, a3, sa) ^ __builtin_amdgcn_alignbyte(b4, b3, sb));
+    la = a4;
+    lb = b4;
+  }
   for (; j + 4 <= len; j += 4) {
     const uint32_t ha = win[++ia], hb = win[++ib];
     diff |= __builtin_amdgcn_alignbyte(ha, la, sa) ^ __builtin_amdgcn_alignbyte(hb, lb, sb);
@@ -464,41 +450,56 @@ __device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __res
   __syncthreads();
 }
 
+// One block per tile. Every record of the tile is tokenised out of LDS by one thread; then the terms of the
+// round are folded: a direct-mapped table in LDS names, per bucket, the earliest occurrence that fell into it,
+// and every other occurrence of the bucket compares its bytes with that one (both are in the window). An
+// occurrence that equals an earlier one of its round only records that occurrence's dictionary entry; the rest
+// (the leaders: ~140 of a LUBM tile's ~550 occurrences) become the tile's dictionary entries, written densely
+// at the tile's own place, [3 * first_rec, 3 * first_rec + leaders): entry indices grow with the position in
+// the text. Only those entries go to the table in HBM afterwards (k_entry_claim), in a kernel without the
+// window in LDS and therefore at full occupancy. Two different terms in one bucket just make two leaders.
 __global__ void __launch_bounds__(TK_THREADS)
 k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask,
            const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash, uint64_t n_rec,
-           DictSlot* __restrict__ ht, uint64_t ht_mask, uint64_t* __restrict__ t_rep /*[field][record]: (offset << 24) | length*/,
-           uint32_t* __restrict__ t_slot /*[field][record]*/, uint8_t* __restrict__ kind, unsigned long long* __restrict__ err,
-           uint32_t* __restrict__ coll /*[0] two strings with one hash, [1] table too full*/) {
+           ulonglong2* __restrict__ ent /*[entry]: x = (offset << 24) | length, y = hash*/,
+           uint32_t* __restrict__ t_entry /*[field][record]: the occurrence's entry*/, uint32_t* __restrict__ tile_leaders /*[tile]*/,
+           uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
   __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 8];
-  __shared__ uint16_t starts[TK_STARTS];
+  __shared__ uint32_t occ_info[3 * TK_ROUND];  // window offset | length << 16 of the round's occurrences
+  __shared__ uint32_t table[TK_BUCKETS];       // earliest occurrence per bucket; afterwards the leaders' ranks (16 bits each)
+  __shared__ uint16_t starts[TK_ROUND];
   __shared__ uint32_t scan_lds[8];
   const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
   const uint32_t first_rec = tile_first[blockIdx.x];
   const uint32_t n_here = tile_first[blockIdx.x + 1] - first_rec;
-  if (n_here == 0) return;  // block-uniform
+  if (n_here == 0) {  // block-uniform
+    if (threadIdx.x == 0) tile_leaders[blockIdx.x] = 0;
+    return;
+  }
   // stage [tile0 - TK_PRE, tile0 + TK_WIN) clipped to the text; bytes outside read as '\n'
   const uint64_t avail = n - tile0;
   const uint32_t win_bytes = avail < (uint64_t)TK_WIN ? (uint32_t)avail : (uint32_t)TK_WIN;
-  stage_window(win, text, n, tile0);
   // record starts of this tile, in order. Positions are window offsets (tile byte i is at TK_PRE + i).
   const uint32_t seg = TK_PRE + threadIdx.x * LS_PER_THREAD;  // thread t owns starts at [seg, seg + 128)
   uint32_t smask[4] = {0, 0, 0, 0};  // bit i of the 128: a record starts at byte i of this thread's segment
-  uint32_t at0;
-  {
+  {  // requested before the window is staged: the masks travel together with the text
     const uint32_t seg_tile = threadIdx.x * LS_PER_THREAD;
     if (seg_tile < win_bytes) {
       const uint4 mv = *reinterpret_cast<const uint4*>(chunk_mask + ((tile0 + seg_tile) >> 4));  // 8 chunk masks = 128 bits
       smask[0] = mv.x; smask[1] = mv.y; smask[2] = mv.z; smask[3] = mv.w;
     }
+  }
+  stage_window(win, text, n, tile0);
+  uint32_t at0;
+  {
     const uint32_t cnt = __popc(smask[0]) + __popc(smask[1]) + __popc(smask[2]) + __popc(smask[3]);
     uint32_t total;
     at0 = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);
     if (__syncthreads_or(total != n_here)) {  // the masks and the counts come from one kernel: cannot differ
-      if (threadIdx.x == 0) atomicMin(err, (unsigned long long)tile0);
+      if (threadIdx.x == 0) { atomicMin(err, (unsigned long long)tile0); tile_leaders[blockIdx.x] = 0; }
       for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
         const uint64_t r = (uint64_t)first_rec + lr;
-        for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = 0; t_slot[k * n_rec + r] = 0; }
+        for (int k = 0; k < 3; ++k) t_entry[k * n_rec + r] = kNoEntry;
         kind[r] = 0;
       }
       return;
@@ -506,209 +507,302 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
   }
   const uint32_t limit = TK_PRE + win_bytes;           // one past the last staged text byte
   const bool window_is_eof = tile0 + win_bytes >= n;   // staged window reaches the end of the text
-  // The starts are listed TK_STARTS at a time; only a tile of very short lines needs a second round.
-  for (uint32_t base = 0; base < n_here; base += TK_STARTS) {  // block-uniform
-  if (base) __syncthreads();
-  {
-    uint32_t at = at0 - base;  // wraps below the round's range and fails the bound check there
+  uint32_t leaders_before = 0;                         // leaders of the tile's earlier rounds
+  // One record per thread and round; only a tile of very short lines needs a second round.
+  for (uint32_t base = 0; base < n_here; base += TK_ROUND) {  // block-uniform
+    if (base) __syncthreads();
+    {
+      uint32_t at = at0 - base;  // wraps below the round's range and fails the bound check there
 #pragma unroll
-    for (int wd = 0; wd < 4; ++wd) {
-      uint32_t m = smask[wd];
-      while (m) {
-        const int bit = __ffs((int)m) - 1;
-        m &= m - 1;
-        if (at < (uint32_t)TK_STARTS) starts[at] = (uint16_t)(seg + wd * 32 + bit);
-        ++at;
+      for (int wd = 0; wd < 4; ++wd) {
+        uint32_t m = smask[wd];
+        while (m) {
+          const int bit = __ffs((int)m) - 1;
+          m &= m - 1;
+          if (at < (uint32_t)TK_ROUND) starts[at] = (uint16_t)(seg + wd * 32 + bit);
+          ++at;
+        }
       }
+      for (uint32_t i = threadIdx.x; i < (uint32_t)TK_BUCKETS; i += TK_THREADS) table[i] = ~0u;
     }
-  }
-  __syncthreads();
-  const uint32_t round_end = n_here - base < (uint32_t)TK_STARTS ? n_here : base + TK_STARTS;
-  for (uint32_t lr = base + threadIdx.x; lr < round_end; lr += TK_THREADS) {
-    const uint32_t p0 = starts[lr - base];
-    const uint64_t gstart = tile0 + (p0 - TK_PRE);
+    __syncthreads();
+    const uint32_t lr = base + threadIdx.x;
+    const bool has = lr < n_here;
     RecordOut out;
     out.bad = false;
-    // Fast path: "<s> <p> <o> ." shaped lines. Anything else -- a field ended by something that is not
-    // blank, control characters, a line that is too short or runs past the window, non-ASCII bytes where
-    // the last two units are cut -- is left to the reference-exact slow path, which also reports errors.
+    out.kind = 0;
+    for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 0; }
     bool odd = false;
-    uint32_t b[3], e[3];
-    TermHash hs(seed), hp(seed), ho(seed);
-    b[0] = p0;
-    e[0] = scan_token(win, p0, hs);
-    // The home slots of subject and predicate are requested as soon as their hashes are known: the answers
-    // travel while the rest of the line is scanned in LDS (subject and predicate are never trimmed further).
-    const uint64_t h_early0 = hs.finish(e[0] - b[0]);
-    const uint4 sv_early0 = *reinterpret_cast<const uint4*>(&ht[h_early0 & ht_mask]);
-    uint32_t p = e[0];
-    odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
-    ++p;
-    if (lds_byte(win, p) <= 0x20) {  // more than one blank between the fields: rare
-      while (p < limit && is_jws(lds_byte(win, p))) ++p;
-      odd |= lds_byte(win, p) <= 0x20;
-    }
-    b[1] = p;
-    e[1] = scan_token(win, p, hp);
-    const uint64_t h_early1 = hp.finish(e[1] - b[1]);
-    const uint4 sv_early1 = *reinterpret_cast<const uint4*>(&ht[h_early1 & ht_mask]);
-    p = e[1];
-    odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
-    ++p;
-    if (lds_byte(win, p) <= 0x20) {
-      while (p < limit && is_jws(lds_byte(win, p))) ++p;
-      odd |= (lds_byte(win, p) <= 0x20) && !is_eol(lds_byte(win, p));  // an empty object is fine
-    }
-    b[2] = p;
-    {  // end of line: first LF / CR at or after the object's first byte, four words per round
-      uint32_t i = p >> 2;
-      const uint32_t sh = p & 3;
-      uint32_t lo = win[i];
-      uint32_t v0, v1, v2, v3, m0, m1, m2, m3;
-      for (;;) {
-        const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
-        v0 = __builtin_amdgcn_alignbyte(w1, lo, sh);
-        v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-        v2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-        v3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
-        m0 = eol_candidates(v0); m1 = eol_candidates(v1); m2 = eol_candidates(v2); m3 = eol_candidates(v3);
-        if (m0 | m1 | m2 | m3) break;
-        i += 4;
-        lo = w4;
+    uint32_t b[3] = {0, 0, 0}, len[3] = {0, 0, 0};
+    if (has) {
+      const uint32_t p0 = starts[threadIdx.x];
+      const uint64_t gstart = tile0 + (p0 - TK_PRE);
+      // Fast path: "<s> <p> <o> ." shaped lines. Anything else -- a field ended by something that is not
+      // blank, control characters, a line that is too short or runs past the window, non-ASCII bytes where
+      // the last two units are cut -- is left to the reference-exact slow path, which also reports errors.
+      uint32_t e[3];
+      TermHash hs(seed), hp(seed), ho(seed);
+      b[0] = p0;
+      e[0] = scan_token(win, p0, hs);
+      uint32_t p = e[0];
+      odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
+      ++p;
+      if (lds_byte(win, p) <= 0x20) {  // more than one blank between the fields: rare
+        while (p < limit && is_jws(lds_byte(win, p))) ++p;
+        odd |= lds_byte(win, p) <= 0x20;
       }
-      uint32_t v = v0, m = m0, base = 0;
-      if (!m0) { v = v1; m = m1; base = 1; if (!m1) { v = v2; m = m2; base = 2; if (!m2) { v = v3; m = m3; base = 3; } } }
-      const uint32_t k = (uint32_t)(__ffs((int)m) - 1) >> 3;
-      odd |= !is_eol((uint8_t)(v >> (8 * k)));  // a VT / FF inside the object
-      e[2] = 4 * (i + base) + sh + k;
-    }
-    odd |= (e[2] > limit) | ((e[2] == limit) & !window_is_eof);  // the line runs past the staged window
-    if (!odd) {
-      // dropRight(2) then trim
-      if (e[2] - b[2] >= 2) {
-        odd |= ((lds_byte(win, e[2] - 1) | lds_byte(win, e[2] - 2)) & 0x80) != 0;
-        e[2] -= 2;
-      } else {
-        e[2] = b[2];
+      b[1] = p;
+      e[1] = scan_token(win, p, hp);
+      p = e[1];
+      odd |= !is_jws(lds_byte(win, p)) | (p >= limit);
+      ++p;
+      if (lds_byte(win, p) <= 0x20) {
+        while (p < limit && is_jws(lds_byte(win, p))) ++p;
+        odd |= (lds_byte(win, p) <= 0x20) && !is_eol(lds_byte(win, p));  // an empty object is fine
       }
-      while (e[2] > b[2] && lds_byte(win, e[2] - 1) <= 0x20) --e[2];
-      while (b[2] < e[2] && lds_byte(win, b[2]) <= 0x20) ++b[2];
-    }
-    if (odd) {
-      tokenise_record_slow(text, n, gstart, seed, out);
-    } else {
-      {  // object hash, four words per round
-        uint32_t q = b[2], i = q >> 2;
-        const uint32_t sh = q & 3;
+      b[2] = p;
+      {  // end of line: first LF / CR at or after the object's first byte, four words per round
+        uint32_t i = p >> 2;
+        const uint32_t sh = p & 3;
         uint32_t lo = win[i];
-        for (; q + 16 <= e[2]; q += 16, i += 4) {
+        uint32_t v0, v1, v2, v3, m0, m1, m2, m3;
+        for (;;) {
           const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
-          ho.add_word(__builtin_amdgcn_alignbyte(w1, lo, sh));
-          ho.add_word(__builtin_amdgcn_alignbyte(w2, w1, sh));
-          ho.add_word(__builtin_amdgcn_alignbyte(w3, w2, sh));
-          ho.add_word(__builtin_amdgcn_alignbyte(w4, w3, sh));
+          v0 = __builtin_amdgcn_alignbyte(w1, lo, sh);
+          v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+          v2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+          v3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+          m0 = eol_candidates(v0); m1 = eol_candidates(v1); m2 = eol_candidates(v2); m3 = eol_candidates(v3);
+          if (m0 | m1 | m2 | m3) break;
+          i += 4;
           lo = w4;
         }
-        for (; q + 4 <= e[2]; q += 4, ++i) {
-          const uint32_t hi = win[i + 1];
-          ho.add_word(__builtin_amdgcn_alignbyte(hi, lo, sh));
-          lo = hi;
+        uint32_t v = v0, m = m0, wbase = 0;
+        if (!m0) { v = v1; m = m1; wbase = 1; if (!m1) { v = v2; m = m2; wbase = 2; if (!m2) { v = v3; m = m3; wbase = 3; } } }
+        const uint32_t k = (uint32_t)(__ffs((int)m) - 1) >> 3;
+        odd |= !is_eol((uint8_t)(v >> (8 * k)));  // a VT / FF inside the object
+        e[2] = 4 * (i + wbase) + sh + k;
+      }
+      odd |= (e[2] > limit) | ((e[2] == limit) & !window_is_eof);  // the line runs past the staged window
+      if (!odd) {
+        // dropRight(2) then trim
+        if (e[2] - b[2] >= 2) {
+          odd |= ((lds_byte(win, e[2] - 1) | lds_byte(win, e[2] - 2)) & 0x80) != 0;
+          e[2] -= 2;
+        } else {
+          e[2] = b[2];
         }
-        if (q < e[2]) ho.add_word(__builtin_amdgcn_alignbyte(win[i + 1], lo, sh) & ((1u << (8 * (e[2] - q))) - 1u));
+        while (e[2] > b[2] && lds_byte(win, e[2] - 1) <= 0x20) --e[2];
+        while (b[2] < e[2] && lds_byte(win, b[2]) <= 0x20) ++b[2];
       }
-      const uint32_t len[3] = {e[0] - b[0], e[1] - b[1], e[2] - b[2]};
-      out.hash[0] = h_early0;
-      out.hash[1] = h_early1;
-      out.hash[2] = ho.finish(len[2]);
-      for (int k = 0; k < 3; ++k) out.rep[k] = ((tile0 + (b[k] - TK_PRE)) << kRepLenBits) | len[k];
-      uint8_t kd = 0;
-      if (len[1] == kTypeLen && out.hash[1] == type_hash) {  // hash first, then the proof, a word at a time
-        const uint32_t* tw = reinterpret_cast<const uint32_t*>(c_rdf_type);
-        bool eq = true;
+      if (odd) {
+        tokenise_record_slow(text, n, gstart, seed, out);
+      } else {
+        {  // object hash, four words per round
+          uint32_t q = b[2], i = q >> 2;
+          const uint32_t sh = q & 3;
+          uint32_t lo = win[i];
+          for (; q + 16 <= e[2]; q += 16, i += 4) {
+            const uint32_t w1 = win[i + 1], w2 = win[i + 2], w3 = win[i + 3], w4 = win[i + 4];
+            ho.add_word(__builtin_amdgcn_alignbyte(w1, lo, sh));
+            ho.add_word(__builtin_amdgcn_alignbyte(w2, w1, sh));
+            ho.add_word(__builtin_amdgcn_alignbyte(w3, w2, sh));
+            ho.add_word(__builtin_amdgcn_alignbyte(w4, w3, sh));
+            lo = w4;
+          }
+          for (; q + 4 <= e[2]; q += 4, ++i) {
+            const uint32_t hi = win[i + 1];
+            ho.add_word(__builtin_amdgcn_alignbyte(hi, lo, sh));
+            lo = hi;
+          }
+          if (q < e[2]) ho.add_word(__builtin_amdgcn_alignbyte(win[i + 1], lo, sh) & ((1u << (8 * (e[2] - q))) - 1u));
+        }
+        for (int k = 0; k < 3; ++k) len[k] = e[k] - b[k];
+        out.hash[0] = hs.finish(len[0]);
+        out.hash[1] = hp.finish(len[1]);
+        out.hash[2] = ho.finish(len[2]);
+        for (int k = 0; k < 3; ++k) out.rep[k] = ((tile0 + (b[k] - TK_PRE)) << kRepLenBits) | len[k];
+        uint8_t kd = 0;
+        if (len[1] == kTypeLen && out.hash[1] == type_hash) {  // hash first, then the proof, a word at a time
+          const uint32_t* tw = reinterpret_cast<const uint32_t*>(c_rdf_type);
+          bool eq = true;
 #pragma unroll
-        for (int i = 0; i < kTypeLen / 4; ++i) eq &= lds_word(win, b[1] + 4 * i) == tw[i];
-        eq &= lds_byte(win, b[1] + kTypeLen - 1) == (uint8_t)c_rdf_type[kTypeLen - 1];
-        if (eq) kd = 1;
+          for (int i = 0; i < kTypeLen / 4; ++i) eq &= lds_word(win, b[1] + 4 * i) == tw[i];
+          eq &= lds_byte(win, b[1] + kTypeLen - 1) == (uint8_t)c_rdf_type[kTypeLen - 1];
+          if (eq) kd = 1;
+        }
+        if (kd == 0 && len[2] && lds_byte(win, b[2]) == '"') kd = 2;
+        out.kind = kd;
       }
-      if (kd == 0 && len[2] && lds_byte(win, b[2]) == '"') kd = 2;
-      out.kind = kd;
+      if (out.bad) atomicMin(err, (unsigned long long)gstart);
     }
-    const uint64_t r = (uint64_t)first_rec + lr;
-    uint32_t slot[3] = {0, 0, 0};
-    if (out.bad) {
-      atomicMin(err, (unsigned long long)gstart);
-      for (int k = 0; k < 3; ++k) { out.rep[k] = 0; out.hash[k] = 0; }  // 0 is no term's hash
-      out.kind = 0;
-    }
-    // Dictionary: claim the three terms' slots, and compare each term with the occurrence that held its slot
-    // before (its own bytes are still in LDS; the holder's are somewhere else in the text).
-    // A few terms (predicates, classes, a subject's run of records) fill a wave many times over. Their lanes
-    // would all hit one slot, with atomics while the tiles in flight race for the earliest occurrence, and the
-    // L2 carries such atomics out one lane at a time: a bounded number of rounds folds the most frequent
-    // hashes of the wave onto their first lane (the earliest in the text), whose occurrence then stands in
-    // as the holder for the others.
-    const int lane = threadIdx.x & 63;
-    const bool valid = !out.bad;
-    uint64_t holder[3];
+    // ---- the round's terms folded onto their earliest occurrence
+    const bool good = has && !out.bad;
+    const uint32_t my = 3 * threadIdx.x;  // occurrence numbers grow with the position in the text
+    bool in_table[3], lead[3];
+    uint32_t bucket[3], owner[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const uint64_t h = out.hash[k];
-      int leader = -1;
-      uint64_t todo = __ballot(valid);
-#pragma unroll 1
-      for (int round = 0; round < 4 && todo; ++round) {
-        const int l = __ffsll((long long)todo) - 1;
-        const uint64_t hl = __shfl(h, l, 64);
-        const bool same = valid && h == hl;
-        if (same && lane != l) leader = l;
-        todo &= ~__ballot(same);
+      in_table[k] = good && !odd && len[k] < 65536u;  // bytes in the window (a slow-path record's need not be)
+      lead[k] = good;
+      owner[k] = my + k;
+      bucket[k] = (uint32_t)(((out.hash[k] >> 32) * (uint64_t)TK_BUCKETS) >> 32);
+      if (in_table[k]) {
+        occ_info[my + k] = b[k] | (len[k] << 16);
+        atomicMin(&table[bucket[k]], my + k);
       }
-      holder[k] = kNoHolder;
-      if (valid && leader < 0) {
-        // the usual case (the term is known) is answered by one load; lowering the representative needs no answer
-        uint4 sv;
-        if (k == 0 && !odd) sv = sv_early0;
-        else if (k == 1 && !odd) sv = sv_early1;
-        else sv = *reinterpret_cast<const uint4*>(&ht[h & ht_mask]);
-        const uint64_t key = ((uint64_t)sv.y << 32) | sv.x, val = ((uint64_t)sv.w << 32) | sv.z;
-        if (key == h && val != kNoHolder) {
-          slot[k] = (uint32_t)(h & ht_mask);
-          holder[k] = val;
-          if (val > out.rep[k]) atomicMin((unsigned long long*)&ht[h & ht_mask].val, (unsigned long long)out.rep[k]);
-        } else {
-          slot[k] = claim_slot(ht, ht_mask, h, out.rep[k], holder[k], coll + 1);
-        }
-      }
-      const int src = leader >= 0 ? leader : lane;
-      const uint32_t slot_l = __shfl(slot[k], src, 64);
-      const uint64_t rep_l = __shfl(out.rep[k], src, 64);
-      if (leader >= 0) { slot[k] = slot_l; holder[k] = rep_l; }
     }
-    if (valid) {
-      bool differ = false;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (!in_table[k]) continue;
+      const uint32_t o = table[bucket[k]];
+      if (o == my + k) continue;
+      const uint32_t info = occ_info[o];
+      if ((info >> 16) == len[k] && diff_lds_lds(win, b[k], info & 0xFFFFu, len[k]) == 0) { lead[k] = false; owner[k] = o; }
+    }
+    const uint32_t mine_cnt = (uint32_t)lead[0] + (uint32_t)lead[1] + (uint32_t)lead[2];
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(mine_cnt, scan_lds, total);  // its barriers end the reads of `table`
+    uint16_t* rank16 = reinterpret_cast<uint16_t*>(table);
+    uint32_t rk[3] = {ex, ex + (uint32_t)lead[0], ex + (uint32_t)lead[0] + (uint32_t)lead[1]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (lead[k] && in_table[k]) rank16[my + k] = (uint16_t)rk[k];
+    __syncthreads();
+    const uint64_t ebase = 3ull * first_rec + leaders_before;
+    if (has) {
+      const uint64_t r = (uint64_t)first_rec + lr;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        if (holder[k] == kNoHolder || holder[k] == out.rep[k]) continue;
-        const uint64_t len = out.rep[k] & ((1ull << kRepLenBits) - 1);
-        if (len != (holder[k] & ((1ull << kRepLenBits) - 1))) { differ = true; continue; }
-        const uint64_t own = out.rep[k] >> kRepLenBits;
-        const uint8_t* hb = text + (holder[k] >> kRepLenBits);
-        const uint64_t hold = holder[k] >> kRepLenBits;
-        const bool own_in = own >= tile0 && own + len <= tile0 + win_bytes;
-        const bool hold_in = hold >= tile0 && hold + len <= tile0 + win_bytes;  // e.g. the wave's first lane with this term
-        if (own_in && hold_in) differ |= diff_lds_lds(win, (uint32_t)(own - tile0) + TK_PRE, (uint32_t)(hold - tile0) + TK_PRE, (uint32_t)len) != 0;
-        else if (own_in) differ |= diff_lds_global(win, (uint32_t)(own - tile0) + TK_PRE, (uint32_t)len, hb) != 0;
-        else differ |= diff_global(text + own, hb, len) != 0;  // a record that ran past the staged window
+        if (good && !lead[k]) rk[k] = rank16[owner[k]];
+        if (lead[k]) ent[ebase + rk[k]] = make_ulonglong2(out.rep[k], out.hash[k]);
+        t_entry[k * n_rec + r] = good ? (uint32_t)(ebase + rk[k]) : kNoEntry;  // field-major: coalesced
       }
-      if (differ) coll[0] = 1;
+      kind[r] = good ? out.kind : (uint8_t)0;
     }
-    for (int k = 0; k < 3; ++k) { t_rep[k * n_rec + r] = out.rep[k]; t_slot[k * n_rec + r] = slot[k]; }  // field-major: coalesced
-    kind[r] = out.kind;
+    leaders_before += total;
   }
-  }
+  if (threadIdx.x == 0) tile_leaders[blockIdx.x] = leaders_before;
 }
 
 // ---- 3. dictionary ---------------------------------------------------------------------------------
+// The kernels over the tiles' entries give one wave to a tile: its entries are [3 * first_rec, + leaders).
+constexpr int EN_TILES_PER_BLOCK = 4;
+
+// Every entry claims / finds the slot of its hash and lowers the slot's representative to the smallest
+// (offset, length) word, i.e. the first occurrence in the text: ids do not depend on timing.
+// An entry that finds an earlier representative r published in its slot can never be the first occurrence: it
+// is compared with r byte by byte at once, both read from the text (flag 0). An entry that lowered the
+// representative, or claimed the slot, may be the first (flag 2): k_entry_first decides when all claims have
+// landed, and compares it with the final representative if it is not. So every entry but the representative has
+// been compared with an entry of its slot that lies earlier in the text: with the comparisons inside the tiles
+// all occurrences that share a slot carry one string, or a collision is reported.
+constexpr uint8_t kMaybeFirst = 2;
+__global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
+k_entry_claim(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
+              const uint8_t* __restrict__ text, const ulonglong2* __restrict__ ent, DictSlot* __restrict__ ht, uint64_t mask,
+              uint32_t* __restrict__ e_slot, uint8_t* __restrict__ first, uint32_t* __restrict__ coll /*[0] collision, [1] overflow*/) {
+  const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint64_t base = 3ull * tile_first[tile];
+  const uint32_t range = 3 * (tile_first[tile + 1] - tile_first[tile]);
+  const uint32_t L = tile_leaders[tile];
+  for (uint32_t i = threadIdx.x & 63; i < range; i += 64) {
+    uint8_t f = 0;
+    if (i < L) {
+      const ulonglong2 en = ent[base + i];
+      const uint64_t mine = en.x, h = en.y;
+      uint64_t slot = h & mask, holder = kNoHolder;
+      uint32_t probes = 0;
+      for (; probes < kMaxProbes; ++probes) {
+        const uint4 sv = *reinterpret_cast<const uint4*>(&ht[slot]);  // key and representative in one load
+        uint64_t cur = ((uint64_t)sv.y << 32) | sv.x;
+        if (cur == 0) {
+          cur = atomicCAS((unsigned long long*)&ht[slot].key, 0ull, (unsigned long long)h);
+          if (cur == 0 || cur == h) {
+            atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+            f = kMaybeFirst;
+            break;
+          }
+        } else if (cur == h) {
+          const uint64_t r = ((uint64_t)sv.w << 32) | sv.z;
+          if (r == kNoHolder || r > mine) {
+            atomicMin((unsigned long long*)&ht[slot].val, (unsigned long long)mine);
+            f = kMaybeFirst;
+          } else {
+            holder = r;
+          }
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
+      if (probes == kMaxProbes) { coll[1] = 1; slot = 0; }
+      e_slot[base + i] = (uint32_t)slot;
+      if (holder != kNoHolder) {
+        const uint64_t lm = mine & ((1ull << kRepLenBits) - 1);
+        if (lm != (holder & ((1ull << kRepLenBits) - 1)) ||
+            diff_global_wide(text + (mine >> kRepLenBits), text + (holder >> kRepLenBits), (uint32_t)lm)) coll[0] = 1;
+      }
+    }
+    first[base + i] = f;
+  }
+}
+
+// first[x] = 1 when entry x is its slot's representative (the earliest occurrence of its term in the text).
+// Only the entries k_entry_claim left undecided are looked at.
+__global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
+k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
+              const uint8_t* __restrict__ text, const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot,
+              const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
+  const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint64_t base = 3ull * tile_first[tile];
+  const uint32_t L = tile_leaders[tile];
+  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) {
+    if (first[base + i] != kMaybeFirst) continue;
+    const uint64_t mine = ent[base + i].x, r = ht[e_slot[base + i]].val;
+    const uint8_t f = mine == r;
+    if (!f) {
+      const uint64_t lm = mine & ((1ull << kRepLenBits) - 1);
+      if (lm != (r & ((1ull << kRepLenBits) - 1)) || diff_global_wide(text + (mine >> kRepLenBits), text + (r >> kRepLenBits), (uint32_t)lm)) *collision = 1;
+    }
+    first[base + i] = f;
+  }
+}
+
+// The representatives get their ids (their rank among the representatives, i.e. ids grow with the place of a
+// term's first occurrence in the text); the slot now maps hash -> id.
+__global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
+k_entry_assign(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
+               const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot, const uint8_t* __restrict__ first,
+               const uint32_t* __restrict__ first_scan, DictSlot* __restrict__ ht, uint32_t* __restrict__ term_len,
+               uint64_t* __restrict__ term_src) {
+  const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint64_t base = 3ull * tile_first[tile];
+  const uint32_t L = tile_leaders[tile];
+  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) {
+    if (!first[base + i]) continue;
+    const uint32_t id = first_scan[base + i];
+    const uint64_t rep = ent[base + i].x;
+    ht[e_slot[base + i]].val = id;
+    term_len[id] = (uint32_t)(rep & ((1ull << kRepLenBits) - 1));
+    term_src[id] = rep >> kRepLenBits;
+  }
+}
+
+// entry -> id, in place of the entry's slot
+__global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
+k_entry_to_id(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
+              const DictSlot* __restrict__ ht, uint32_t* __restrict__ e_slot_then_id) {
+  const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint64_t base = 3ull * tile_first[tile];
+  const uint32_t L = tile_leaders[tile];
+  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) e_slot_then_id[base + i] = (uint32_t)ht[e_slot_then_id[base + i]].val;
+}
+
 __global__ void __launch_bounds__(256) k_ht_clear(DictSlot* __restrict__ ht, uint64_t cap) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
     *reinterpret_cast<uint4*>(&ht[i]) = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -739,24 +833,6 @@ k_dict_insert(const uint64_t* __restrict__ t_hash, const uint64_t* __restrict__ 
   const int src = at_or_below ? 63 - __clzll((long long)at_or_below) : lane;
   const uint32_t run_slot = __shfl((uint32_t)slot, src, 64);
   if (valid) t_slot[i] = run_slot;
-}
-
-// first[i] = 1 when occurrence i is its slot's representative (the earliest occurrence of its term in the text).
-// Four occurrences per lane: 32- and 16-byte loads, the four slot reads in flight together, one 4-byte store.
-__global__ void __launch_bounds__(256)
-k_dict_first(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t_slot, uint64_t n_occ, const DictSlot* __restrict__ ht,
-             uint8_t* __restrict__ first) {
-  const uint64_t i0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
-  if (i0 >= n_occ) return;
-  if (i0 + 4 <= n_occ) {
-    const ulonglong2 r01 = *reinterpret_cast<const ulonglong2*>(t_rep + i0), r23 = *reinterpret_cast<const ulonglong2*>(t_rep + i0 + 2);
-    const uint4 sl = *reinterpret_cast<const uint4*>(t_slot + i0);
-    const uint64_t v0 = ht[sl.x].val, v1 = ht[sl.y].val, v2 = ht[sl.z].val, v3 = ht[sl.w].val;
-    *reinterpret_cast<uint32_t*>(first + i0) = (uint32_t)(r01.x == v0) | ((uint32_t)(r01.y == v1) << 8) | ((uint32_t)(r23.x == v2) << 16) |
-                                              ((uint32_t)(r23.y == v3) << 24);
-  } else {
-    for (uint64_t i = i0; i < n_occ; ++i) first[i] = t_rep[i] == ht[t_slot[i]].val;
-  }
 }
 
 // One occurrence in twelve is a first one: a lane looks at four flags at once and does the work of those set.
@@ -790,14 +866,14 @@ k_dict_assign(const uint64_t* __restrict__ t_rep, const uint32_t* __restrict__ t
 // no atomics are needed (read-modify-write atomics are carried out lane by lane in the L2, and the records
 // of one subject sit in neighbouring lanes). The check before each store only saves stores.
 __global__ void __launch_bounds__(256)
-k_encode(const uint32_t* __restrict__ t_slot, const DictSlot* __restrict__ ht, const uint8_t* __restrict__ kind,
+k_encode(const uint32_t* __restrict__ t_entry, const uint32_t* __restrict__ e_id, const uint8_t* __restrict__ kind,
          uint32_t n_rec, uint32_t* __restrict__ S, uint32_t* __restrict__ P, uint32_t* __restrict__ O,
          uint8_t* __restrict__ is_vertex, uint8_t* __restrict__ has_edge, uint8_t* __restrict__ is_literal,
          uint8_t* __restrict__ is_pred) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rec) return;
-  const uint32_t s = (uint32_t)ht[t_slot[r]].val, p = (uint32_t)ht[t_slot[(uint64_t)n_rec + r]].val,
-                 o = (uint32_t)ht[t_slot[2ull * n_rec + r]].val;
+  // an occurrence names its tile's entry for the term, the entry carries the id
+  const uint32_t s = e_id[t_entry[r]], p = e_id[t_entry[(uint64_t)n_rec + r]], o = e_id[t_entry[2ull * n_rec + r]];
   S[r] = s; P[r] = p; O[r] = o;
   auto set = [](uint8_t* a, uint32_t id) { if (!a[id]) a[id] = 1; };
   set(is_pred, p);
@@ -1423,6 +1499,18 @@ hipEvent_t pooled_event(dx_ctx* ctx, size_t i) {
   return ctx->part_events[i];
 }
 // out[i] = in[i * stride]
+// one block adds up a short array (the tiles' entry counts)
+__global__ void __launch_bounds__(1024) k_sum_u32(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[16];
+  uint32_t v = 0;
+  for (uint32_t i = 4 * threadIdx.x; i + 4 <= n; i += 4096) { const uint4 q = *reinterpret_cast<const uint4*>(in + i); v += q.x + q.y + q.z + q.w; }
+  if (threadIdx.x == 0) for (uint32_t i = n & ~3u; i < n; ++i) v += in[i];
+  v = wave_reduce_u32(v);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += lds[w]; *out = t; }
+}
+
 __global__ void k_pick_strided(const uint32_t* __restrict__ in, size_t stride, int n, uint32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[(size_t)i * stride];
@@ -1439,7 +1527,7 @@ struct StageTimer {
 
 // Stages 10 and 11 are the two big kernels inside "dictionary", timed on their own.
 const char* const kStageNames[12] = {"line_scan", "tokenise_hash", "dictionary", "string_pool", "vertex_masks", "sort_triples",
-                                     "place", "split_partitions", "node_index", "vp_index", "dict_clear_kernel", "dict_first_kernel"};
+                                     "place", "split_partitions", "node_index", "vp_index", "dict_clear_kernel", "dict_claim_kernel"};
 
 void dict_build_table(dx_ctx* ctx) {
   Dictionary& d = ctx->dict;
@@ -1701,7 +1789,7 @@ void globalise_dictionary(dx_ctx* ctx, uint32_t n_rec, uint32_t* S, uint32_t* P,
     DX_HIP(hipStreamSynchronize(s));
     // every rank sees the same entries, so every rank takes the same turns here
     if (h_coll[1]) {
-      if (cap >= 4ull * E && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 4 slots per entry");
+      if (cap >= 8ull * E && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 8 slots per entry");
       cap <<= 1;
       ht = DevBuf<DictSlot>(pool, cap);
       continue;
@@ -1812,24 +1900,29 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
 
   const uint64_t n_occ = 3ull * n_rec;
   if (n_occ >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32/3 records on one GPU");
-  DevBuf<uint64_t> t_rep(pool, n_occ);
+  // Dictionary entries: the tokeniser folds the occurrences of a tile onto their first one there, and only those
+  // (a quarter of the occurrences on LUBM) go to the table. Tile t's entries sit at [3 * first record of t, + leaders of t).
+  DevBuf<ulonglong2> ent(pool, n_occ);
+  DevBuf<uint32_t> t_entry(pool, n_occ), e_slot(pool, n_occ), tile_leaders(pool, ntiles + 1);
   DevBuf<uint8_t> kind(pool, n_rec);
-  DevBuf<uint32_t> t_slot(pool, n_occ);
-  // Table capacity: 1.5 slots per record to start with (LUBM-like data has ~0.3 distinct terms per
-  // record); a probe chain that runs too long reports overflow and the build restarts twice as large.
-  // 4 slots per record can never overflow (at most 3 distinct terms per record).
+  // Table capacity: at least half a slot per record to start with (LUBM-like data has ~0.26 distinct terms per
+  // record, so the table is at most half full and, at LUBM-100, small enough to stay in the last-level cache while
+  // the entries gather from it); a probe chain that runs too long reports overflow and the build restarts twice
+  // as large (at 8 slots per record it is at most three eighths full and chains of 2^10 do not occur).
   uint64_t cap = 1024;
-  while (cap < n_rec + n_rec / 2) cap <<= 1;
+  while (cap < n_rec / 2) cap <<= 1;
   DevBuf<DictSlot> ht(pool, cap);
   DevBuf<uint8_t> first(pool, n_occ);
   DevBuf<uint32_t> first_scan(pool, n_occ);
   DevBuf<uint32_t> coll(pool, 2);  // [0] true hash collision, [1] table overflow
   uint64_t seed = 0x243F6A8885A308D3ull;
   uint32_t n_terms = 0;
-  float ms_tok = 0, ms_clear = 0, ms_first = 0;
+  float ms_tok = 0, ms_clear = 0, ms_claim = 0;
+  const unsigned en_blocks = (ntiles + EN_TILES_PER_BLOCK - 1) / EN_TILES_PER_BLOCK;
   for (;;) {
     const hipEvent_t e0 = pooled_event(ctx, 0), e1 = pooled_event(ctx, 1), e2 = pooled_event(ctx, 2), e3 = pooled_event(ctx, 3);
-    // ---- 2./3. tokenise + hash + dictionary slots + byte comparison, in one pass over the text
+    // ---- 2./3. tokenise + hash + folding inside the tiles in one pass over the text; then the tiles' entries
+    // claim their slots, and every entry that is not its term's first occurrence is compared with that one
     DX_HIP(hipEventRecord(e0, s));
     hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
     DX_HIP(hipMemsetAsync(coll.p, 0, 8, s));
@@ -1837,23 +1930,30 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     if (n_rec)
       hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed,
                          hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec,
-                         ht.p, cap - 1, t_rep.p, t_slot.p, kind.p, err.p, coll.p);
+                         ent.p, t_entry.p, tile_leaders.p, kind.p, err.p);
     DX_HIP(hipEventRecord(e2, s));
-    if (n_occ) hipLaunchKernelGGL(k_dict_first, dim3(blocks((n_occ + 3) / 4)), dim3(256), 0, s, t_rep.p, t_slot.p, n_occ, ht.p, first.p);
+    if (n_rec)
+      hipLaunchKernelGGL(k_entry_claim, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, text, ent.p,
+                         ht.p, cap - 1, e_slot.p, first.p, coll.p);
     DX_HIP(hipEventRecord(e3, s));
+    if (n_rec)
+      hipLaunchKernelGGL(k_entry_first, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, text,
+                         ent.p, e_slot.p, ht.p, first.p, coll.p);
     exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
+    if (n_rec) hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, s, tile_leaders.p, ntiles, d_total.p + 1);
     unsigned long long h_err = ~0ull;
     uint32_t h_coll[2] = {0, 0};
     fetch.add(&h_err, err.p, 8);
     fetch.add(h_coll, coll.p, 8);
     fetch.add(&n_terms, d_total.p, 4);
+    if (n_rec) fetch.add(&st.n_dict_entries, d_total.p + 1, 4);
     fetch.sync();
-    DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_first, e2, e3));
+    DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_claim, e2, e3));
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
                                         " (empty line, fewer than three fields, or a term of 16 MiB or more)");
     if (h_coll[1]) {  // table too full for its probe bound
-      if (cap >= 4ull * n_rec && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 4 slots per record");
+      if (cap >= 8ull * n_rec && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 8 slots per record");
       cap <<= 1;
       ht = DevBuf<DictSlot>(pool, cap);
       continue;
@@ -1877,9 +1977,10 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DX_HIP(hipMemsetAsync(fact.p, 0, fact.bytes(), s));
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
-    hipLaunchKernelGGL(k_dict_assign, dim3(blocks((n_occ + 3) / 4)), dim3(256), 0, s, t_rep.p, t_slot.p, first.p, first_scan.p, n_occ, ht.p,
-                       term_len.p, term_src.p);
-    hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_slot.p, ht.p, kind.p, n_rec, S.p, P.p, O.p,
+    hipLaunchKernelGGL(k_entry_assign, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, ent.p,
+                       e_slot.p, first.p, first_scan.p, ht.p, term_len.p, term_src.p);
+    hipLaunchKernelGGL(k_entry_to_id, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, ht.p, e_slot.p);
+    hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_entry.p, e_slot.p, kind.p, n_rec, S.p, P.p, O.p,
                        fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
   }
   hipLaunchKernelGGL(k_merge_flags, dim3(blocks(n_terms)), dim3(256), 0, s, fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad,
@@ -1888,7 +1989,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   d.ht = std::move(ht);
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
-  t_slot.reset(); first.reset(); first_scan.reset();
+  t_entry.reset(); e_slot.reset(); first.reset(); first_scan.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
@@ -1901,7 +2002,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * n_terms)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
                                   (uint64_t)n_terms, d.pool.p);
   tm.mark();
-  t_rep.reset(); term_src.reset(); term_len.reset();
+  ent.reset(); term_src.reset(); term_len.reset();
 
   // ---- several GPUs: one dictionary for all ranks; the per-term facts are recomputed over its ids and
   // summed over the ranks (a fact holds if it holds anywhere). The time lands in the vertex_masks stage.
@@ -2271,7 +2372,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DX_HIP(hipEventElapsedTime(&total, tm.ev.front(), tm.ev.back()));
   st.ms_total = total;
   st.ms_stage[10] = ms_clear;
-  st.ms_stage[11] = ms_first;
+  st.ms_stage[11] = ms_claim;
   ps.valid = true;
 }
 

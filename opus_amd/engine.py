@@ -48,10 +48,10 @@ class PartStats(ctypes.Structure):
     _fields_ = [("n_bytes", c_uint64), ("n_triples", c_uint64), ("n_unique", c_uint64), ("n_terms", c_uint64),
                 ("n_vertices", c_uint64), ("n_edges", c_uint64), ("n_rows", c_uint64), ("n_node_index", c_uint64),
                 ("n_vp_index", c_uint64), ("n_predicates", c_uint32), ("n_tables", c_uint32),
-                ("hash_retries", c_uint32), ("reserved", c_uint32), ("ms_total", c_double), ("ms_stage", c_double * 12)]
+                ("hash_retries", c_uint32), ("n_dict_entries", c_uint32), ("ms_total", c_double), ("ms_stage", c_double * 12)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("ms_stage", "reserved")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "ms_stage"}
         lib = load_library()
         d["ms_stage"] = {lib.dx_part_stage_name(i).decode(): self.ms_stage[i] for i in range(12)
                          if lib.dx_part_stage_name(i)}
