@@ -58,6 +58,15 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
     assert stats == ref["statistics"]
     pstat = T.load_partition_stats((cwd / "LUBM_local" / "partition_stat.txt_4_bal").read_text())
     assert pstat == ref["partition_stat"]
+    # statTables.txt, read the way QueryOptimizer.main does (QueryOptimizer.scala:270-276): "<table> <rows>" per line,
+    # keyed by the view name the translated SQL uses; the values are the row counts of the vertical-partition tables
+    stat_tables = {}
+    for line in (cwd / "LUBM_local" / "statTables.txt").read_text().split("\n"):
+        f = line.split(" ")
+        if len(f) >= 2:
+            stat_tables["table" + f[0].replace("-", "_").replace("=", "_E_").strip()] = float(f[1])
+    assert stat_tables == {query_oracle.clean_table_name(part + "-" + sub): float(len(rows)) for (part, sub), rows in ref["vp"].items()}
+    assert all(k.startswith("table0000") and "_3_E_" in k for k in stat_tables)
 
     # second run: output exists, stage is skipped (DAP.scala:86)
     p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM", "4", base, str(cwd / "instances.nt"), "x"], cwd=cwd, capture_output=True, text=True)

@@ -57,6 +57,51 @@ def test_lubm_query_counts_and_bindings(loaded, lubm1, name):
     assert rows == ref["rows"], name  # sorted decoded bindings, bit-exact
 
 
+@pytest.fixture(scope="module")
+def loaded_swat(lubm1_swat):
+    """The same for the second namespace the reference ships queries for (queries/lubm10240)."""
+    from opus_amd import lubm
+    from opus_amd.engine import Engine
+    from opus_amd.host import translator as T
+    from parity_util import assert_same_as_oracle, engine_artifacts
+    e = Engine(0)
+    e.partition_text(lubm1_swat["bytes"], lubm1_swat["class_index"], 4)
+    art = engine_artifacts(e)
+    assert_same_as_oracle(art, lubm1_swat["oracle"])
+    ni = {}
+    for u, c in art["node_index"]:
+        ni.setdefault(u, []).append(c)
+    ci = T.load_class_index(lubm1_swat["class_index"])
+    translated = {}
+    for name, text in lubm.queries(1).items():
+        translated[name] = T.translate_query(name, text, lambda u: ni.get(u, []), ci, art["partition_stat"])
+        assert translated[name] is not None, name
+    yield e, translated
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["Q%d.txt" % i for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14)])
+def test_lubm10240_folder_query_counts_and_bindings(loaded_swat, lubm1_swat, name):
+    """The 13 queries of queries/lubm10240 (swat namespace) over data generated in that namespace."""
+    from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
+    from oracle.query_oracle import run_query
+    e, translated = loaded_swat
+    ref = run_query(lubm1_swat["oracle"]["vp"], translated[name])
+    res, load_rows = _run_file(e, translated[name], DX_QUERY_COUNT)
+    assert res.count == ref["count"], name
+    assert load_rows == ref["load_data"]
+    res_b, _ = _run_file(e, translated[name], DX_QUERY_BINDINGS)
+    rows, cols = res_b.rows()
+    assert res_b.count == ref["count"] and cols == ref["columns"]
+    assert rows == ref["rows"], name  # sorted decoded bindings, bit-exact
+
+
+def test_lubm10240_folder_answers_are_not_all_empty(loaded_swat, lubm1_swat):
+    from oracle.query_oracle import run_query
+    _, translated = loaded_swat
+    assert sum(run_query(lubm1_swat["oracle"]["vp"], translated[n])["count"] > 0 for n in translated) >= 10
+
+
 def test_reference_translated_q2_example_parses_and_runs(loaded):
     """The one translated file the reference carries (QueryOptimizer.scala:282) names partitions
     00001/00002/00004 of an N >= 5 run; against this 4-partition data its tables do not exist."""
