@@ -215,6 +215,7 @@ void dx_free(dx_ctx* ctx) {
   ctx->pool.trim();
   if (ctx->q_ev0) { (void)hipEventDestroy(ctx->q_ev0); (void)hipEventDestroy(ctx->q_ev1); }
   if (ctx->q_host) (void)hipHostFree(ctx->q_host);
+  if (ctx->q_counters) (void)hipFree(ctx->q_counters);
   if (ctx->part_host) (void)hipHostFree(ctx->part_host);
   for (hipEvent_t e : ctx->part_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
@@ -1126,7 +1127,7 @@ uint64_t dx_result_count(dx_result* r) { return r ? r->global_count : 0; }
 uint64_t dx_result_local_rows(dx_result* r) { return r ? r->count : 0; }
 int dx_result_columns(dx_result* r) { return r ? (int)r->names.size() : 0; }
 const char* dx_result_column_name(dx_result* r, int i) { return (r && i >= 0 && i < (int)r->names.size()) ? r->names[i].c_str() : ""; }
-double dx_result_device_ms(dx_result* r) { return r ? r->device_ms : 0; }
+double dx_result_device_ms(dx_result* r) { return r ? dx::result_device_ms(r) : 0; }
 
 int dx_result_fetch_ids(dx_result* r, int64_t* ids, int sorted) {
   if (!r) return DX_E_INVAL;

@@ -15,6 +15,7 @@
 //     its optimistic capacity is detected there (its counter holds the exact size needed) and the
 //     statement is run again with that capacity.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <functional>
@@ -51,48 +52,59 @@ struct ArmDev {
   int nsrc;
   int src[3];      // 0 = s, 1 = o, 2 = constant
   int src_ci[3];
+  long long src_val[3];  // the constant's id (projected constants are never looked up: they carry ids of their own)
   int direct;      // the tuple's columns are stored as they are (rows received from other ranks): no filters
   const int64_t* d[3];
 };
 
-struct ConstArgs {
-  char bytes[kConstBytes];
-  uint32_t off[kMaxConsts + 1];
-  long long preset[kMaxConsts];  // LLONG_MIN = look the string up, anything else = the id to use
-  uint64_t hash[kMaxConsts];     // term hash of the string, computed on the host
+template <int kBytes, int kCount>
+struct ConstArgsT {
+  char bytes[kBytes];
+  uint32_t off[kCount + 1];
+  long long preset[kCount];  // LLONG_MIN = look the string up, anything else = the id to use
+  uint64_t hash[kCount];     // term hash of the string, computed on the host
   int n;
 };
+using ConstArgs = ConstArgsT<kConstBytes, kMaxConsts>;
 
 __device__ __forceinline__ uint64_t hash_key(int64_t a) { return mix64((uint64_t)a * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull); }
 __device__ __forceinline__ uint64_t hash_key2(int64_t a, int64_t b) { return mix64(hash_key(a) ^ ((uint64_t)b * 0xC2B2AE3D27D4EB4Full)); }
 
 // Constants -> term ids, on the device, so the host never waits for them. One wave per constant:
-// lane 0 walks the probe chain, then all lanes compare the bytes eight at a time.
-__device__ __forceinline__ void resolve_const(const ConstArgs& ca, int i, int lane, uint64_t seed, const DictSlot* __restrict__ ht,
-                                              uint64_t mask, const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
-                                              int64_t* __restrict__ out) {
-  if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) { if (lane == 0) out[i] = ca.preset[i]; return; }
+// lane 0 walks the probe chain, then all lanes compare the bytes eight at a time. Returns the id in every lane.
+template <class CA>
+__device__ __forceinline__ long long resolve_const_value(const CA& ca, int i, int lane, const DictSlot* __restrict__ ht,
+                                                         uint64_t mask, const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off) {
+  if (ca.preset[i] != (-0x7FFFFFFFFFFFFFFFll - 1)) return ca.preset[i];
   const uint32_t b = ca.off[i], e = ca.off[i + 1], len = e - b;
   const uint64_t h = ca.hash[i];
   long long id = -1;
   if (lane == 0) {
     uint64_t slot = h & mask;
     for (;;) {
-      const uint64_t cur = ht[slot].key;
+      const uint4 sv = *reinterpret_cast<const uint4*>(&ht[slot]);  // key and id in one load
+      const uint64_t cur = ((uint64_t)sv.y << 32) | sv.x;
       if (cur == 0) break;
-      if (cur == h) { id = (long long)(uint32_t)ht[slot].val; break; }  // one slot per hash
+      if (cur == h) { id = (long long)sv.z; break; }  // one slot per hash
       slot = (slot + 1) & mask;
     }
   }
   id = __shfl(id, 0, 64);
-  if (id < 0) { if (lane == 0) out[i] = -1; return; }
+  if (id < 0) return -1;
   const uint64_t pb = pool_off[id], pl = pool_off[id + 1] - pb;
   bool same = pl == len;
   if (same) {
     for (uint32_t j = lane; j < len; j += 64) same &= pool[pb + j] == (uint8_t)ca.bytes[b + j];
   }
   same = __all(same);
-  if (lane == 0) out[i] = same ? id : -1;
+  return same ? id : -1;
+}
+template <class CA>
+__device__ __forceinline__ void resolve_const(const CA& ca, int i, int lane, uint64_t seed, const DictSlot* __restrict__ ht,
+                                              uint64_t mask, const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
+                                              int64_t* __restrict__ out) {
+  const long long v = resolve_const_value(ca, i, lane, ht, mask, pool, pool_off);
+  if (lane == 0) out[i] = v;
 }
 __global__ void __launch_bounds__(64)
 k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask,
@@ -105,15 +117,131 @@ k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, u
 __global__ void __launch_bounds__(256)
 k_query_init(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask, const uint8_t* __restrict__ pool,
              const uint64_t* __restrict__ pool_off, int64_t* __restrict__ consts, unsigned long long* __restrict__ counters, int n_counters,
-             uint32_t* __restrict__ heads, uint64_t n_heads) {
+             uint32_t* __restrict__ heads, uint64_t n_heads, unsigned long long* preset_counter = nullptr, unsigned long long preset_value = 0) {
   if ((int)blockIdx.x < ca.n && threadIdx.x < 64) resolve_const(ca, blockIdx.x, threadIdx.x, seed, ht, mask, pool, pool_off, consts);
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
   if (t < (uint64_t)n_counters) counters[t] = 0;
+  if (t == 0 && preset_counter) *preset_counter = preset_value;
   uint4* h4 = reinterpret_cast<uint4*>(heads);  // the arena is a multiple of four words
   for (uint64_t i = t; i < n_heads / 4; i += stride) h4[i] = make_uint4(kNil, kNil, kNil, kNil);
 }
 
-__device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, uint32_t i, int64_t v[3]) {
+// ---- a statement's first and last kernel ------------------------------------------------------------------
+// A short statement is a handful of kernels of a few microseconds each, and every kernel boundary costs as much
+// as such a kernel. So there is no kernel of its own for the preparation and none for the hand-over:
+//   * the statement's FIRST kernel (a scan) carries a Prologue: its
+//     blocks resolve the statement's constants for the later kernels, set the hash-join heads of every step to
+//     "empty", and each block resolves the one or two constants its own scan filters by for itself (the other
+//     blocks' answers are not visible inside one kernel);
+//   * the statement's LAST kernel carries an Epilogue: the block that finishes last (a ticket per block) stores
+//     the row counters to the pinned host block, then the statement's number, which the host is watching, and
+//     zeroes the counters and the ticket for the next statement (they live in the context, zero between
+//     statements, so nobody has to clear them first).
+constexpr int kProBytes = 1024, kProConsts = 16;
+using ProConsts = ConstArgsT<kProBytes, kProConsts>;
+struct Prologue {
+  int enabled;
+  ProConsts ca;
+  const DictSlot* ht;
+  uint64_t mask;
+  const uint8_t* pool;
+  const uint64_t* pool_off;
+  int64_t* consts;
+  uint32_t* heads;
+  uint64_t n_heads;                       // multiple of four
+};
+struct Epilogue {
+  int enabled;
+  unsigned long long* counters;
+  int n;
+  unsigned long long* ticket;      // [0] main, [1 + i] one per kSubTickets: arrivals and partial sums, zero between statements
+  unsigned long long* host_counters;
+  unsigned long long* host_seq;
+  unsigned long long seq;
+};
+
+// Values of the arm's two filter constants. In the statement's first kernel they are looked up by this block
+// (waves 1 and 2) while wave 0 and the grid as a whole do the statement's preparation. Contains a barrier:
+// every thread of the block must call it.
+__device__ __forceinline__ void stmt_prologue(const Prologue& pro, int fs, int fo, const int64_t* __restrict__ consts, int64_t& want_s,
+                                              int64_t& want_o) {
+  if (!pro.enabled) {
+    want_s = fs >= 0 ? consts[fs] : 0;
+    want_o = fo >= 0 ? consts[fo] : 0;
+    return;
+  }
+  __shared__ long long own[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    for (int c = blockIdx.x; c < pro.ca.n; c += gridDim.x) resolve_const(pro.ca, c, lane, 0, pro.ht, pro.mask, pro.pool, pro.pool_off, pro.consts);
+  } else if (wave == 1) {
+    const long long v = fs >= 0 ? resolve_const_value(pro.ca, fs, lane, pro.ht, pro.mask, pro.pool, pro.pool_off) : 0;
+    if (lane == 0) own[0] = v;
+  } else if (wave == 2) {
+    const long long v = fo >= 0 ? resolve_const_value(pro.ca, fo, lane, pro.ht, pro.mask, pro.pool, pro.pool_off) : 0;
+    if (lane == 0) own[1] = v;
+  }
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  uint4* h4 = reinterpret_cast<uint4*>(pro.heads);
+  for (uint64_t i = t; i < pro.n_heads / 4; i += stride) h4[i] = make_uint4(kNil, kNil, kNil, kNil);
+  __syncthreads();
+  want_s = own[0];
+  want_o = own[1];
+}
+
+// Every thread of the block must call it, after the block's last update of a row counter. `add` (thread 0's
+// value counts) is this block's contribution to *add_to, or add_to is null.
+// Arrivals are counted in two levels (blocks on kSubTickets words, the last arrival of each word on the main one):
+// the L2 carries out atomics on one word one after another, about 8 ns apiece, and a few thousand blocks on one
+// word would take longer than the scan they end. A counting kernel's block totals ride in the same words, the
+// arrivals above bit kTicketShift and the sum below it, so that one atomic per block does both and the block
+// that arrives last holds the total without any ordering between two addresses (a fence here makes every block
+// write back and invalidate its L2, which cost more than the scan). Row counters that kernels claim output rows
+// from need no fence either: a block has the answers of its own claims before it arrives here.
+constexpr int kSubTickets = 64;
+constexpr int kTicketShift = 44;
+__device__ __forceinline__ void stmt_epilogue(const Epilogue& ep, unsigned long long add = 0, unsigned long long* add_to = nullptr) {
+  if (!ep.enabled) {
+    if (add_to && threadIdx.x == 0 && add) atomicAdd(add_to, add);
+    return;
+  }
+  __shared__ int last;
+  __shared__ unsigned long long total_s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned sub = blockIdx.x % kSubTickets;
+    const unsigned long long expect = (gridDim.x - sub + kSubTickets - 1) / kSubTickets;  // blocks b < gridDim.x with b % kSubTickets == sub
+    const unsigned long long one = 1ull << kTicketShift, low = one - 1;
+    int l = 0;
+    unsigned long long v = atomicAdd(&ep.ticket[1 + sub], one | (add_to ? add : 0ull)) + (one | (add_to ? add : 0ull));
+    if ((v >> kTicketShift) == expect) {  // last of this word: v's low part is the sum of its blocks
+      __hip_atomic_store(&ep.ticket[1 + sub], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long words = gridDim.x < (unsigned)kSubTickets ? gridDim.x : (unsigned)kSubTickets;
+      v = atomicAdd(&ep.ticket[0], one | (v & low)) + (one | (v & low));
+      if ((v >> kTicketShift) == words) {
+        l = 1;
+        total_s = v & low;
+        __hip_atomic_store(&ep.ticket[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    last = l;
+  }
+  __syncthreads();
+  if (!last) return;
+  if ((int)threadIdx.x < ep.n) {
+    unsigned long long v = __hip_atomic_load(&ep.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (add_to && add_to == &ep.counters[threadIdx.x]) v += total_s;  // a counter other kernels of the step have added to as well
+    __hip_atomic_store(&ep.host_counters[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&ep.counters[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ep.host_seq, ep.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// `pre`: the values of the filtered columns were requested earlier (pre_s / pre_o) and are not loaded again
+__device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, int64_t want_s, int64_t want_o, uint32_t i,
+                                        int64_t v[3], bool pre = false, int64_t pre_s = 0, int64_t pre_o = 0) {
   if (a.direct) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -122,8 +250,8 @@ __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restri
   }
   // columnar: the filtered column is read first, the other one only for rows that pass
   int64_t s = 0, o = 0;
-  if (a.fo >= 0) { o = a.o[i]; if (o != consts[a.fo]) return false; }
-  if (a.fs >= 0) { s = a.s[i]; if (s != consts[a.fs]) return false; }
+  if (a.fo >= 0) { o = pre ? pre_o : a.o[i]; if (o != want_o) return false; }
+  if (a.fs >= 0) { s = pre ? pre_s : a.s[i]; if (s != want_s) return false; }
   bool need_s = false, need_o = false;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -132,7 +260,7 @@ __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restri
   if (need_o && a.fo < 0) o = a.o[i];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    if (k < a.nsrc) v[k] = a.src[k] == 0 ? s : a.src[k] == 1 ? o : consts[a.src_ci[k]];
+    if (k < a.nsrc) v[k] = a.src[k] == 0 ? s : a.src[k] == 1 ? o : a.src_val[k];
   return true;
 }
 
@@ -142,13 +270,27 @@ __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restri
 // usual case -- one constant filter, nothing else read -- it has eight loads in flight at a time.
 constexpr unsigned kCountBlocks = 512;
 __global__ void __launch_bounds__(256)
-k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* __restrict__ total) {
+k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* __restrict__ total, Prologue pro, Epilogue ep) {
+  int64_t want_s, want_o;
   uint32_t c = 0;
   const uint32_t nthreads = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
   if (!a.direct && ((a.fo >= 0) != (a.fs >= 0))) {
     const int64_t* __restrict__ col = a.fo >= 0 ? a.o : a.s;
-    const int64_t want = consts[a.fo >= 0 ? a.fo : a.fs];
     uint64_t i = t;  // 64-bit: the stride must not wrap on a table of nearly 2^32 rows
+    // the first loads do not depend on the constant: they travel while the prologue looks it up
+    int64_t v0[8];
+    const bool first_batch = i + 7ull * nthreads < a.rows;
+    if (first_batch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v0[j] = col[i + j * nthreads];
+    }
+    stmt_prologue(pro, a.fs, a.fo, consts, want_s, want_o);
+    const int64_t want = a.fo >= 0 ? want_o : want_s;
+    if (first_batch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c += v0[j] == want ? 1u : 0u;
+      i += 8ull * nthreads;
+    }
     for (; i + 7ull * nthreads < a.rows; i += 8ull * nthreads) {
       int64_t v[8];
 #pragma unroll
@@ -158,15 +300,16 @@ k_scan_count(ArmDev a, const int64_t* __restrict__ consts, unsigned long long* _
     }
     for (; i < a.rows; i += nthreads) c += col[i] == want ? 1u : 0u;
   } else {
+    stmt_prologue(pro, a.direct ? -1 : a.fs, a.direct ? -1 : a.fo, consts, want_s, want_o);
     for (uint64_t i = t; i < a.rows; i += nthreads) {
       int64_t v[3];
-      c += arm_row(a, consts, (uint32_t)i, v) ? 1u : 0u;
+      c += arm_row(a, consts, want_s, want_o, (uint32_t)i, v) ? 1u : 0u;
     }
   }
   __shared__ uint32_t lds[8];
   uint32_t block_total;
   (void)block_excl_scan_256<uint32_t>(c, lds, block_total);
-  if (threadIdx.x == 0 && block_total) atomicAdd(total, (unsigned long long)block_total);
+  stmt_epilogue(ep, block_total, total);
 }
 
 // Output rows are claimed from one counter. Thousands of waves claiming for themselves are served one after
@@ -189,16 +332,31 @@ __device__ __forceinline__ unsigned long long block_claim(uint32_t mine, unsigne
 // Filtered scan that appends the projected tuple to `out` (first relation of a plan).
 template <int kRowsPerThread>
 __global__ void __launch_bounds__(256)
-k_scan_emit(ArmDev a, const int64_t* __restrict__ consts, RelDev out, unsigned long long* __restrict__ out_count) {
+k_scan_emit(ArmDev a, const int64_t* __restrict__ consts, RelDev out, unsigned long long* __restrict__ out_count, Prologue pro, Epilogue ep) {
   constexpr int kTileRows = 256 * kRowsPerThread;
   const uint32_t ntiles = (a.rows + kTileRows - 1) / kTileRows;
+  int64_t want_s, want_o;
+  // In the statement's first kernel the filtered columns of the block's first tile are requested before the
+  // prologue looks the constants up: the two waits overlap.
+  int64_t pre_s[kRowsPerThread], pre_o[kRowsPerThread];
+  const bool pre = pro.enabled && !a.direct && blockIdx.x < ntiles;
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      const uint32_t i = blockIdx.x * kTileRows + j * 256 + threadIdx.x;
+      pre_s[j] = (a.fs >= 0 && i < a.rows) ? a.s[i] : 0;
+      pre_o[j] = (a.fo >= 0 && i < a.rows) ? a.o[i] : 0;
+    }
+  }
+  stmt_prologue(pro, a.direct ? -1 : a.fs, a.direct ? -1 : a.fo, consts, want_s, want_o);
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform
     int64_t v[kRowsPerThread][3];
     uint32_t hits = 0, n = 0;
+    const bool use_pre = pre && tile == blockIdx.x;
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
       const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
-      if (i < a.rows && arm_row(a, consts, i, v[j])) { hits |= 1u << j; ++n; }
+      if (i < a.rows && arm_row(a, consts, want_s, want_o, i, v[j], use_pre, pre_s[j], pre_o[j])) { hits |= 1u << j; ++n; }
     }
     uint32_t before;
     unsigned long long pos = block_claim(n, out_count, before) + before;
@@ -213,6 +371,7 @@ k_scan_emit(ArmDev a, const int64_t* __restrict__ consts, RelDev out, unsigned l
         ++pos;
       }
   }
+  stmt_epilogue(ep);
 }
 
 struct BuildArgs {
@@ -247,6 +406,8 @@ struct ProbeArgs {
   RelDev out;       // columns: I's, then the new ones
   unsigned long long* out_count;
   int count_only;
+  unsigned long long* small_failed;  // k_probe<.., true>: bit `step` is raised when the intermediate does not fit the LDS table
+  int step;
 };
 
 // Streams one base-table arm and probes the intermediate's hash table. nkey == 0 is the cross product.
@@ -255,10 +416,49 @@ struct ProbeArgs {
 __device__ __forceinline__ bool probe_match(const ProbeArgs& p, uint32_t r, int64_t k0, int64_t k1) {
   return p.nkey == 0 || (p.I.col[p.key_col[0]][r] == k0 && (p.nkey < 2 || p.I.col[p.key_col[1]][r] == k1));
 }
-template <int kRowsPerThread>
-__global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
+// kLds: the intermediate is expected to be small (a few rows after a constant filter, as in most steps of the LUBM
+// statements). Then there is no build kernel and no table in HBM: every block enters the intermediate's keys into a
+// chained table of its own in LDS (the rows are read once per block, from cache), and the probes never leave
+// the CU. An intermediate that turns out larger than kLdsRows raises the step's bit in *p.small_failed, emits
+// nothing, and the host runs the statement again with the table in HBM for that step.
+constexpr int kLdsRows = 1024, kLdsHeads = 2048;
+template <int kRowsPerThread, bool kLds>
+__global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
   constexpr int kTileRows = 256 * kRowsPerThread;
+  __shared__ int64_t lds_k0[kLds ? kLdsRows : 1], lds_k1[kLds ? kLdsRows : 1];
+  __shared__ uint32_t lds_heads[kLds ? kLdsHeads : 1];
+  __shared__ uint16_t lds_next[kLds ? kLdsRows : 1];
   const uint32_t nI = rel_rows(p.I);
+  const int64_t want_s = (!p.arm.direct && p.arm.fs >= 0) ? p.consts[p.arm.fs] : 0, want_o = (!p.arm.direct && p.arm.fo >= 0) ? p.consts[p.arm.fo] : 0;
+  if (kLds) {
+    if (nI > (uint32_t)kLdsRows) {  // block-uniform
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the answer is waited for: the flag has landed before this block arrives at the epilogue's ticket
+        const unsigned long long before = atomicOr(p.small_failed, 1ull << p.step);
+        asm volatile("" ::"v"(before));
+      }
+      stmt_epilogue(ep);
+      return;
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLdsHeads; i += 256) lds_heads[i] = kNil;
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < nI; r += 256) {
+      const int64_t k0 = p.I.col[p.key_col[0]][r], k1 = p.nkey == 2 ? p.I.col[p.key_col[1]][r] : 0;
+      lds_k0[r] = k0;
+      lds_k1[r] = k1;
+      const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
+      lds_next[r] = (uint16_t)atomicExch(&lds_heads[(uint32_t)h & (kLdsHeads - 1)], r);  // kNil's low half marks the end
+    }
+    __syncthreads();
+  }
+  auto chain_next = [&](uint32_t r) -> uint32_t {
+    if (kLds) { const uint32_t nx = lds_next[r]; return nx == 0xFFFFu ? kNil : nx; }
+    return p.next[r];
+  };
+  auto matches = [&](uint32_t r, int64_t k0, int64_t k1) -> bool {
+    if (kLds) return lds_k0[r] == k0 && (p.nkey < 2 || lds_k1[r] == k1);
+    return probe_match(p, r, k0, k1);
+  };
   const uint32_t ntiles = (p.arm.rows + kTileRows - 1) / kTileRows;
   unsigned long long local = 0;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform
@@ -269,13 +469,13 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
     for (int j = 0; j < kRowsPerThread; ++j) {
       const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
       head[j] = kNil;
-      if (i < p.arm.rows && arm_row(p.arm, p.consts, i, v[j])) {
+      if (i < p.arm.rows && arm_row(p.arm, p.consts, want_s, want_o, i, v[j])) {
         if (p.nkey == 0) {
           head[j] = nI ? 0u : kNil;
         } else {
           const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
           const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
-          head[j] = p.heads[(uint32_t)h & p.hmask];
+          head[j] = kLds ? lds_heads[(uint32_t)h & (kLdsHeads - 1)] : p.heads[(uint32_t)h & p.hmask];
         }
       }
     }
@@ -286,8 +486,8 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
       nhit[j] = 0;
       if (p.nkey == 0) { nhit[j] = head[j] != kNil ? nI : 0u; n += nhit[j]; continue; }
       const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
-      for (uint32_t r = head[j]; r != kNil; r = p.next[r])
-        if (probe_match(p, r, k0, k1)) {
+      for (uint32_t r = head[j]; r != kNil; r = chain_next(r))
+        if (matches(r, k0, k1)) {
           if (!nhit[j]) hit[j] = r;
           ++nhit[j];
         }
@@ -302,8 +502,8 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
       const int64_t k0 = p.nkey ? v[j][p.key_src[0]] : 0, k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
       // the usual row has one match, remembered from the counting walk; only several matches walk the chain again
       const bool single = p.nkey != 0 && nhit[j] == 1;
-      for (uint32_t r = single ? hit[j] : head[j]; r != kNil; r = single ? kNil : (p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : p.next[r])) {
-        if (!single && !probe_match(p, r, k0, k1)) continue;
+      for (uint32_t r = single ? hit[j] : head[j]; r != kNil; r = single ? kNil : (p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : chain_next(r))) {
+        if (!single && !matches(r, k0, k1)) continue;
         if (pos < p.out.cap) {
           for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
           for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = v[j][p.new_src[c]];
@@ -316,8 +516,10 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p) {
     __shared__ uint64_t lds64[8];
     uint64_t block_total;
     (void)block_excl_scan_256<uint64_t>(local, lds64, block_total);
-    if (threadIdx.x == 0 && block_total) atomicAdd(p.out_count, (unsigned long long)block_total);
+    stmt_epilogue(ep, block_total, p.out_count);
+    return;
   }
+  stmt_epilogue(ep);
 }
 
 // ---- planning ----------------------------------------------------------------------------------------
@@ -328,6 +530,7 @@ struct PlanRel {
     const CatalogTable* t;
     int fs = -1, fo = -1;
     int src[3] = {0, 0, 0}, src_ci[3] = {-1, -1, -1};
+    long long src_val[3] = {0, 0, 0};  // ids of the projected constants
   };
   std::vector<Arm> arms;
   uint64_t rows_upper = 0;       // rows of the arms held here: bounds the local scan output
@@ -457,7 +660,7 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true) {
       if (arm.has_o) a.fo = add_const(arm.o_const, false);
       for (int c = 0; c < r.ncols; ++c) {
         a.src[c] = arm.proj[c].src;
-        if (a.src[c] == 2) a.src_ci[c] = add_const(arm.proj[c].constant, true);
+        if (a.src[c] == 2) { a.src_ci[c] = add_const(arm.proj[c].constant, true); a.src_val[c] = plan.const_preset[a.src_ci[c]]; }
       }
       r.arms.push_back(a);
       r.rows_upper += a.t->rows;
@@ -546,7 +749,7 @@ ArmDev arm_dev(const PlanRel& r, const PlanRel::Arm& a) {
   ArmDev d{};
   d.s = a.t->s; d.o = a.t->o; d.rows = (uint32_t)a.t->rows;
   d.fs = a.fs; d.fo = a.fo; d.nsrc = r.ncols;
-  for (int c = 0; c < 3; ++c) { d.src[c] = a.src[c]; d.src_ci[c] = a.src_ci[c]; }
+  for (int c = 0; c < 3; ++c) { d.src[c] = a.src[c]; d.src_ci[c] = a.src_ci[c]; d.src_val[c] = a.src_val[c]; }
   return d;
 }
 
@@ -560,28 +763,85 @@ unsigned tile_grid(uint64_t rows, int rows_per_thread) {  // kernels that work o
   if (g < 1) g = 1;
   return (unsigned)(g > 4096 ? 4096 : g);
 }
-void launch_scan_emit(hipStream_t s, uint64_t rows, const ArmDev& a, const int64_t* consts, const RelDev& out, unsigned long long* cnt) {
-  if (rows <= kSmallTable) hipLaunchKernelGGL(k_scan_emit<1>, dim3(tile_grid(rows, 1)), dim3(256), 0, s, a, consts, out, cnt);
-  else hipLaunchKernelGGL(k_scan_emit<4>, dim3(tile_grid(rows, 4)), dim3(256), 0, s, a, consts, out, cnt);
+void launch_scan_emit(hipStream_t s, uint64_t rows, const ArmDev& a, const int64_t* consts, const RelDev& out, unsigned long long* cnt,
+                      const Prologue& pro = Prologue{}, const Epilogue& ep = Epilogue{}, unsigned min_grid = 1) {
+  if (rows <= kSmallTable) hipLaunchKernelGGL(k_scan_emit<1>, dim3(std::max(tile_grid(rows, 1), min_grid)), dim3(256), 0, s, a, consts, out, cnt, pro, ep);
+  else hipLaunchKernelGGL(k_scan_emit<4>, dim3(std::max(tile_grid(rows, 4), min_grid)), dim3(256), 0, s, a, consts, out, cnt, pro, ep);
 }
-void launch_probe(hipStream_t s, uint64_t rows, const ProbeArgs& p) {
-  if (rows <= kSmallTable) hipLaunchKernelGGL(k_probe<1>, dim3(tile_grid(rows, 1)), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(k_probe<4>, dim3(tile_grid(rows, 4)), dim3(256), 0, s, p);
+void launch_probe(hipStream_t s, uint64_t rows, const ProbeArgs& p, const Epilogue& ep = Epilogue{}, bool small = false) {
+  if (small) {
+    if (rows <= kSmallTable) hipLaunchKernelGGL((k_probe<1, true>), dim3(tile_grid(rows, 1)), dim3(256), 0, s, p, ep);
+    else hipLaunchKernelGGL((k_probe<4, true>), dim3(tile_grid(rows, 4)), dim3(256), 0, s, p, ep);
+  } else {
+    if (rows <= kSmallTable) hipLaunchKernelGGL((k_probe<1, false>), dim3(tile_grid(rows, 1)), dim3(256), 0, s, p, ep);
+    else hipLaunchKernelGGL((k_probe<4, false>), dim3(tile_grid(rows, 4)), dim3(256), 0, s, p, ep);
+  }
 }
 
 }  // namespace
 
+// device block of a context: row counters and tickets (see Epilogue)
+constexpr size_t kQueryCounterBytes = sizeof(unsigned long long) * (MAXSTEPS + 2 + 1 + kSubTickets);
 // Pinned host block the final counters land in.
 constexpr int kShardedWords = 2 * 64 + 8;
 struct QueryHostBlock {
   unsigned long long counters[MAXSTEPS + 2];
+  unsigned long long seq;                     // number of the statement whose counters these are (written last)
   unsigned long long sharded[kShardedWords];  // several GPUs: row counts per destination rank on their way to the host
 };
 
 // The pinned block and the two events a statement uses, made once per context (dx_init): no statement creates
 // anything, so the entry point that allocates nothing can share this code.
+// The statement's last kernel: the row counters go to the pinned host block by stores from the device, followed
+// by the statement's number. The host watches that word instead of waiting for the stream's completion signal
+// (a copy engine's transfer plus the runtime's wake-up cost more than the statement's kernels for a short one).
+__global__ void __launch_bounds__(64)
+k_publish(const unsigned long long* __restrict__ counters, int n, unsigned long long* host_counters, unsigned long long* host_seq,
+          unsigned long long seq) {
+  if ((int)threadIdx.x < n) __hip_atomic_store(&host_counters[threadIdx.x], counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Waits until the pinned block carries statement `seq`: by watching the word for a while, then through the stream
+// (which also reports a failed kernel). DX_QUERY_WAIT=stream always waits through the stream.
+static void wait_published(dx_ctx* ctx, QueryHostBlock* hb, uint64_t seq) {
+  static const bool spin = [] { const char* e = getenv("DX_QUERY_WAIT"); return !(e && std::string(e) == "stream"); }();
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const volatile unsigned long long* w = &hb->seq;
+    for (uint32_t i = 0;; ++i) {
+      if (*w == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+      __builtin_ia32_pause();
+      if ((i & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  DX_HIP(hipStreamSynchronize(ctx->stream));
+  DX_HIP(hipGetLastError());
+  if (hb->seq != seq) throw DxError(DX_E_HIP, "the statement's counters did not arrive on the host");
+}
+
+double result_device_ms(dx_result* r) {
+  if (r->device_ms >= 0) return r->device_ms;
+  dx_ctx* ctx = r->ctx;
+  r->device_ms = 0;
+  if (ctx && ctx->q_seq == r->timing_seq && ctx->q_ev1) {  // the events have not been recorded again since
+    float ms = 0;
+    if (hipEventSynchronize(ctx->q_ev1) == hipSuccess && hipEventElapsedTime(&ms, ctx->q_ev0, ctx->q_ev1) == hipSuccess) r->device_ms = ms;
+  }
+  return r->device_ms;
+}
+
 void query_context_setup(dx_ctx* ctx) {
-  if (!ctx->q_host) DX_HIP(hipHostMalloc(&ctx->q_host, sizeof(QueryHostBlock), hipHostMallocDefault));
+  if (!ctx->q_host) {
+    DX_HIP(hipHostMalloc(&ctx->q_host, sizeof(QueryHostBlock), hipHostMallocDefault));
+    memset(ctx->q_host, 0, sizeof(QueryHostBlock));
+    DX_HIP(hipHostGetDevicePointer(&ctx->q_host_dev, ctx->q_host, 0));
+  }
+  if (!ctx->q_counters) {  // row counters + the last-block ticket of a statement: zero between statements
+    DX_HIP(hipMalloc(&ctx->q_counters, kQueryCounterBytes));
+    DX_HIP(hipMemset(ctx->q_counters, 0, kQueryCounterBytes));
+  }
   if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }
 }
 
@@ -622,25 +882,40 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
   res->names = plan.select_names;
   res->virtual_terms = plan.virtual_terms;
   try {
-    for (int attempt = 0; attempt <= nsteps + 1; ++attempt) {
+    // The statement's preparation rides in its first kernel and its hand-over in its last (see Prologue / Epilogue)
+    // whenever the constants fit the first kernel's arguments; otherwise a kernel each does them.
+    // steps whose intermediate did not fit the table in LDS the last time this statement ran: remembered per statement text
+    const size_t sql_key = std::hash<std::string>{}(sql);
+    uint64_t regular_steps = 0;
+    {
+      auto it = ctx->q_regular_steps.find(sql_key);
+      if (it != ctx->q_regular_steps.end()) regular_steps = it->second;
+    }
+    const bool fused = ca.n <= kProConsts && off <= (uint32_t)kProBytes && ctx->q_counters && !getenv("DX_QUERY_UNFUSED");
+    for (int attempt = 0; attempt <= 2 * nsteps + 2; ++attempt) {
       if (pool.is_arena()) pool.rewind();  // a re-run with larger buffers starts from the arena's base again
       DevBuf<int64_t> consts(pool, kMaxConsts);
-      DevBuf<unsigned long long> counters(pool, MAXSTEPS + 2);
+      DevBuf<unsigned long long> own_counters;
+      if (!fused) own_counters = DevBuf<unsigned long long>(pool, MAXSTEPS + 2);
+      unsigned long long* const counters_p = fused ? static_cast<unsigned long long*>(ctx->q_counters) : own_counters.p;
       std::vector<std::vector<DevBuf<int64_t>>> step_cols(nsteps);
       std::vector<DevBuf<uint32_t>> tmp32;
-      // The steps are laid out first (buffers, capacities, hash-table sizes) and launched afterwards, behind one
-      // kernel that prepares everything they need: see k_query_init.
-      std::vector<std::function<void()>> launches;
+      // The steps are laid out first (buffers, capacities, hash-table sizes) and launched afterwards: the first
+      // launch is handed the prologue, the last one the epilogue.
+      using Launch = std::function<void(const Prologue&, const Epilogue&, unsigned)>;
+      std::vector<Launch> launches;
       uint64_t heads_words = 0;
       DevBuf<uint32_t> heads_arena;
       RelDev I{};
       std::vector<int> I_cls;
       std::vector<uint64_t> step_cap(nsteps, 0);
+      unsigned long long* preset_counter = nullptr;  // fused: the first relation is a table used in place
+      unsigned long long preset_value = 0;
       for (int k = 0; k < nsteps; ++k) {
         const PlanRel& r = plan.rels[k];
         const bool last = k == nsteps - 1;
         const bool count_only = last && mode == DX_QUERY_COUNT;
-        unsigned long long* cnt = counters.p + k;
+        unsigned long long* cnt = counters_p + k;
         if (k == 0) {
           if (count_only) {
             for (const auto& a : r.arms)
@@ -648,7 +923,9 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
                 const ArmDev ad = arm_dev(r, a);
                 const uint64_t rows = a.t->rows;
                 const int64_t* cp = consts.p;
-                launches.push_back([=] { hipLaunchKernelGGL(k_scan_count, dim3(std::min(scan_grid(rows), kCountBlocks)), dim3(256), 0, s, ad, cp, cnt); });
+                launches.push_back([=](const Prologue& pro, const Epilogue& ep, unsigned) {
+                  hipLaunchKernelGGL(k_scan_count, dim3(std::min(scan_grid(rows), kCountBlocks)), dim3(256), 0, s, ad, cp, cnt, pro, ep);
+                });
               }
             break;
           }
@@ -661,7 +938,8 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
             const CatalogTable* t = r.arms[0].t;
             for (int c = 0; c < r.ncols; ++c) I.col[c] = const_cast<int64_t*>(r.arms[0].src[c] == 0 ? t->s : t->o);
             I.cap = (uint32_t)t->rows;
-            launches.push_back([=] { DX_HIP(hipMemcpyAsync(cnt, &t->rows, 8, hipMemcpyHostToDevice, s)); });
+            if (fused) { preset_counter = cnt; preset_value = t->rows; }
+            else launches.push_back([=](const Prologue&, const Epilogue&, unsigned) { DX_HIP(hipMemcpyAsync(cnt, &t->rows, 8, hipMemcpyHostToDevice, s)); });
             step_cap[k] = t->rows;
           } else {
             const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : r.rows_upper, 1);
@@ -674,7 +952,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
                 const uint64_t rows = a.t->rows;
                 const int64_t* cp = consts.p;
                 const RelDev Iv = I;
-                launches.push_back([=] { launch_scan_emit(s, rows, ad, cp, Iv, cnt); });
+                launches.push_back([=](const Prologue& pro, const Epilogue& ep, unsigned min_grid) { launch_scan_emit(s, rows, ad, cp, Iv, cnt, pro, ep, min_grid); });
               }
           }
           I_cls.assign(r.cls, r.cls + r.ncols);
@@ -701,10 +979,16 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           }
         }
         if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
-        if (pa.nkey > 0) {
+        // An intermediate the planner expects to be small gets its table in LDS, block by block, inside the probe
+        // (k_probe<.., true>); if it is not small after all, the step says so and the statement runs again without.
+        const bool small = fused && pa.nkey > 0 && !(regular_steps & (1ull << k)) &&
+                           k - 1 < (int)plan.est_rows.size() && plan.est_rows[k - 1] <= kLdsRows / 4;
+        pa.small_failed = counters_p + MAXSTEPS + 1;
+        pa.step = k;
+        if (pa.nkey > 0 && !small) {
           // Chained table: any number of heads is correct, fewer only means longer chains. Two heads per row
-          // that is expected (four times the planner's estimate, to be safe), never fewer than an eighth of the
-          // rows that could arrive: the heads of all steps are filled by k_query_init and read at random by the
+          // that is expected (four times the planner's estimate, to be safe), never fewer than a sixteenth of the
+          // rows that could arrive: the heads of all steps are filled before the first scan and read at random by the
           // probes, so a table sized for the buffer's capacity costs time in both when the filters are selective.
           uint64_t expect = I.cap;
           if (k - 1 < (int)plan.est_rows.size())
@@ -721,7 +1005,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           const uint32_t icap = I.cap;
           const uint64_t off_words = my_heads_off;
           DevBuf<uint32_t>* arena = &heads_arena;
-          launches.push_back([=]() mutable {
+          launches.push_back([=](const Prologue&, const Epilogue&, unsigned) mutable {
             ba.heads = arena->p + off_words;
             hipLaunchKernelGGL(k_build, dim3(scan_grid(icap)), dim3(256), 0, s, ba);
           });
@@ -750,27 +1034,67 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           const uint64_t off_words = my_heads_off;
           DevBuf<uint32_t>* arena = &heads_arena;
           ProbeArgs pv = pa;
-          launches.push_back([=]() mutable {
+          launches.push_back([=](const Prologue&, const Epilogue& ep, unsigned) mutable {
             if (off_words != ~0ull) pv.heads = arena->p + off_words;
-            launch_probe(s, rows, pv);
+            launch_probe(s, rows, pv, ep, small);
           });
         }
         I = out;
         for (int c : new_cls) I_cls.push_back(c);
       }
       heads_arena = DevBuf<uint32_t>(pool, std::max<uint64_t>(heads_words, 4));
+      const uint64_t fill_blocks = (heads_words / 4 + 255) / 256;
+      const uint64_t seq = ++ctx->q_seq;
       DX_HIP(hipEventRecord(ev0, s));
-      {
-        const uint64_t fill_blocks = (heads_words / 4 + 255) / 256;
+      if (fused && launches.empty()) {  // nothing to scan at all (every table named is empty): every count is zero
+        for (auto& c : hb->counters) c = 0;
+        DX_HIP(hipEventRecord(ev1, s));
+      } else if (fused) {
+        QueryHostBlock* hd = static_cast<QueryHostBlock*>(ctx->q_host_dev);
+        if (ctx->q_counters_dirty) DX_HIP(hipMemsetAsync(ctx->q_counters, 0, kQueryCounterBytes, s));
+        ctx->q_counters_dirty = true;  // until the last kernel has put them back to zero
+        Prologue pro{};
+        pro.enabled = 1;
+        pro.ca.n = ca.n;
+        memcpy(pro.ca.bytes, ca.bytes, off);
+        for (int i = 0; i < ca.n; ++i) { pro.ca.off[i] = ca.off[i]; pro.ca.preset[i] = ca.preset[i]; pro.ca.hash[i] = ca.hash[i]; }
+        pro.ca.off[ca.n] = ca.off[ca.n];
+        pro.ht = ctx->dict.ht.p; pro.mask = ctx->dict.ht_mask; pro.pool = ctx->dict.pool.p; pro.pool_off = ctx->dict.pool_off.p;
+        pro.consts = consts.p;
+        pro.heads = heads_arena.p; pro.n_heads = heads_words;
+        Epilogue ep{};
+        ep.enabled = 1;
+        ep.counters = counters_p; ep.n = MAXSTEPS + 2;
+        ep.ticket = counters_p + MAXSTEPS + 2;
+        ep.host_counters = hd->counters; ep.host_seq = &hd->seq; ep.seq = seq;
+        const Prologue no_pro{};
+        const Epilogue no_ep{};
+        const unsigned min_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(fill_blocks, 1024));
+        // A table used in place makes the build of step 1 the first kernel, and a kernel cannot set the heads to
+        // "empty" while its other blocks already enter rows: then the preparation is a kernel of its own after all.
+        const bool own_init = preset_counter != nullptr;
+        if (own_init) {
+          const unsigned grid = (unsigned)std::max<uint64_t>(std::max<uint64_t>(ca.n, 1), std::min<uint64_t>(fill_blocks, 2048));
+          hipLaunchKernelGGL(k_query_init, dim3(grid), dim3(256), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
+                             ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters_p, 0, heads_arena.p, heads_words, preset_counter, preset_value);
+        }
+        for (size_t i = 0; i < launches.size(); ++i)
+          launches[i](i == 0 && !own_init ? pro : no_pro, i + 1 == launches.size() ? ep : no_ep, min_grid);
+        DX_HIP(hipEventRecord(ev1, s));
+        wait_published(ctx, hb, seq);
+        ctx->q_counters_dirty = false;
+      } else {
         const unsigned grid = (unsigned)std::max<uint64_t>(std::max<uint64_t>(ca.n, 1), std::min<uint64_t>(fill_blocks, 2048));
         hipLaunchKernelGGL(k_query_init, dim3(grid), dim3(256), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
-                           ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters.p, MAXSTEPS + 2, heads_arena.p, heads_words);
+                           ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters_p, MAXSTEPS + 2, heads_arena.p, heads_words);
+        const Prologue no_pro{};
+        const Epilogue no_ep{};
+        for (auto& f : launches) f(no_pro, no_ep, 1);
+        QueryHostBlock* hd = static_cast<QueryHostBlock*>(ctx->q_host_dev);
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, counters_p, MAXSTEPS + 2, hd->counters, &hd->seq, (unsigned long long)seq);
+        DX_HIP(hipEventRecord(ev1, s));
+        wait_published(ctx, hb, seq);
       }
-      for (auto& f : launches) f();
-      DX_HIP(hipMemcpyAsync(hb->counters, counters.p, sizeof(unsigned long long) * (MAXSTEPS + 2), hipMemcpyDeviceToHost, s));
-      DX_HIP(hipEventRecord(ev1, s));
-      DX_HIP(hipStreamSynchronize(s));
-      DX_HIP(hipGetLastError());
       std::ostringstream explain;
       explain << "parse+plan " << (long)plan_us << " us\n";
       for (int k = 0; k < nsteps; ++k) {
@@ -780,6 +1104,12 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           explain << (a ? " UNION " : "") << r.arms[a].t->view << "[" << r.arms[a].t->rows << " rows"
                   << (r.arms[a].fs >= 0 ? ", s filter" : "") << (r.arms[a].fo >= 0 ? ", o filter" : "") << "]";
         explain << " -> " << hb->counters[k] << " rows\n";
+      }
+      if (fused && hb->counters[MAXSTEPS + 1]) {  // some step's intermediate did not fit its table in LDS
+        regular_steps |= hb->counters[MAXSTEPS + 1];
+        if (ctx->q_regular_steps.size() > 4096) ctx->q_regular_steps.clear();
+        ctx->q_regular_steps[sql_key] = regular_steps;
+        continue;
       }
       bool overflow = false;
       const bool final_counts_only = mode == DX_QUERY_COUNT;
@@ -793,9 +1123,8 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         }
       }
       if (overflow) continue;
-      float ms = 0;
-      DX_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-      res->device_ms = ms;
+      res->device_ms = -1;  // read from the events when asked for, as long as no later statement has recorded them again
+      res->timing_seq = ctx->q_seq;
       res->count = hb->counters[nsteps - 1];
       res->global_count = res->count;
       if (mode == DX_QUERY_BINDINGS) {

@@ -130,6 +130,11 @@ struct dx_ctx {
   dx::DevBuf<uint8_t> qws;
   hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
   void* q_host = nullptr;               // pinned block the final counters of a statement land in
+  void* q_host_dev = nullptr;           // the same block as the device addresses it
+  uint64_t q_seq = 0;                   // statements run on this context so far
+  void* q_counters = nullptr;           // device: a statement's row counters and its last-block ticket, zero between statements
+  std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
+  bool q_counters_dirty = false;        // a statement failed between its first and its last kernel: clear before the next
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
   uint8_t* part_host = nullptr;         // pinned block the partitioner's small results come back through
   size_t part_host_used = 0;
@@ -205,7 +210,8 @@ struct dx_result {
   dx_ctx* ctx = nullptr;
   uint64_t count = 0;         // rows held by this context
   uint64_t global_count = 0;  // rows over all ranks (== count on one GPU)
-  double device_ms = 0;
+  double device_ms = 0;       // -1: not read yet (see result_device_ms)
+  uint64_t timing_seq = 0;    // the statement whose events still hold this result's device time
   bool has_bindings = false;
   std::vector<std::string> names;
   std::vector<dx::DevBuf<int64_t>> cols;   // one per selected column (bindings mode)
@@ -227,6 +233,7 @@ const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t);
 void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
+double result_device_ms(dx_result* r);  // device time of the statement, read from its events when first asked for
 void query_context_setup(dx_ctx* ctx);                      // pinned block + events of the query path, once per context
 void* noalloc_scratch_of_current_device(size_t* bytes);     // the device array behind dx_query_count_noalloc
 uint64_t run_query_count_noalloc(dx_ctx* ctx, const std::string& sql);
