@@ -90,52 +90,42 @@ def parse_translated(text):
     return sql, partitions
 
 
-def cpu_baseline():
-    """The CPU restatement timed on this host's cores, rank 0 only, on a bounded sample of the same
-    workload: the C++ port of the partitioner on LUBM-10, SQLite on LUBM-1 for the 13 queries."""
-    from opus_amd import lubm
-    from opus_amd.host import translator as T
-    from oracle import cpu_port, dap_oracle, query_oracle
-    arr, nt = lubm.generate(0, 10, seed=0, ontology=0, degree_pool=1000)
-    part = cpu_port.run(arr, lubm.class_index_text(8, 0), 8)
-    del arr
-    # the same port on all the host cores this process may use: one block of ten universities per thread,
-    # side by side (the port itself is scalar; ctypes releases the interpreter lock during the call)
-    import concurrent.futures
+def cpu_baseline(arr, n_triples, class_index, n_partitions, plans, gpu_counts):
+    """The CPU restatement (oracle/cpu_port.cpp) timed on this host's cores, rank 0 only, on the benchmark's own
+    data set: the partitioner on one thread and on all the cores this process may use (one shared dictionary), then
+    the 13 translated statements over the restatement's own vertical-partition tables as scans + hash joins + count,
+    keyed on term ids and keyed on the terms' strings (what the reference's Spark plan compares), on one thread and
+    on all. Protocol as for the GPU: tables resident, one untimed run, then the timed count. The counts must equal
+    the GPU's."""
+    from oracle import cpu_port
     threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    blocks = [lubm.generate(10 * (i + 1), 10 * (i + 2), seed=0, ontology=0, degree_pool=1000) for i in range(threads)]
-    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
-        runs = list(ex.map(lambda b: cpu_port.run(b[0], lubm.class_index_text(8, 0), 8), blocks))
-    # the port's own clock covers the partitioning only (it goes on to the instance measures afterwards)
-    all_cores = sum(b[1] for b in blocks) / max(r["seconds"] for r in runs)
-    del blocks
-    arr1, nt1 = lubm.generate(0, 1, seed=0, ontology=0, degree_pool=1000)
-    ci = lubm.class_index_text(8, 0)
-    ref = dap_oracle.run_dap(arr1.tobytes().decode(), ci, 8)  # string-level VP tables for SQLite
-    ni = {}
-    for u, c in ref["node_index"]:
-        ni.setdefault(u, []).append(c)
-    cidx = T.load_class_index(ci)
-    times = []
-    for name, text in lubm.queries(0).items():
-        tr = T.translate_query(name, text, lambda x: ni.get(x, []), cidx, ref["partition_stat"])
-        qm, parts, _ = query_oracle.parse_translated_file(tr)
-        proc = query_oracle.SqliteProcessor(ref["vp"])
-        proc.preload(parts)
-        proc.execute(qm)  # warm-up, as the reference does for its first query
-        t0 = time.perf_counter()
-        proc.execute(qm)
-        times.append((time.perf_counter() - t0) * 1e3)
-    geo = math.exp(sum(math.log(max(t, 1e-6)) for t in times) / len(times))
+    one = cpu_port.run(arr, class_index, n_partitions)
+    ds = cpu_port.Dataset(arr, class_index, n_partitions, threads=threads)   # the same run on all cores; keeps its tables
+    legs = {}
+    for label, t, by_string in (("ids_1_thread", 1, False), ("ids_all_threads", threads, False),
+                                ("strings_1_thread", 1, True), ("strings_all_threads", threads, True)):
+        times = {}
+        for name, (sql, parts) in plans.items():
+            c, _ = ds.count(sql, parts, threads=t, string_keyed=by_string)          # untimed run
+            if c != gpu_counts[name]:
+                raise RuntimeError("CPU restatement counts %d rows for %s, the GPU %d" % (c, name, gpu_counts[name]))
+            c, secs = ds.count(sql, parts, threads=t, string_keyed=by_string)
+            times[name] = secs * 1e3
+        legs[label] = {"geomean_ms": math.exp(sum(math.log(max(v, 1e-6)) for v in times.values()) / len(times)),
+                       "query_ms": times}
+    all_cores = n_triples / ds.seconds
+    ds.close()
     import shutil
     spark = "present" if (shutil.which("java") and shutil.which("spark-submit")) else \
         "absent on this host (no java / spark-submit): the reference itself cannot be timed beside"
-    return {"spark_local": spark, "value": nt / part["seconds"], "unit": "triples/s", "cores": 1, "kind": "port",
-            "sample": "partitioner: oracle/cpu_port.cpp (C++, interned strings, one thread) on LUBM-10 (%d triples, %.1f s); "
-                      "queries: SQLite (one thread) on LUBM-1 (%d triples)" % (nt, part["seconds"], nt1),
-            "query_geomean_ms": geo,
+    return {"spark_local": spark, "value": n_triples / one["seconds"], "unit": "triples/s", "cores": 1, "kind": "port",
+            "sample": "oracle/cpu_port.cpp on the benchmark's own data (%d triples): partitioner on one thread in %.1f s and on %d "
+                      "threads in %.1f s; the 13 statements as scans + hash joins over its tables, counts equal to the GPU's"
+                      % (n_triples, one["seconds"], threads, n_triples / all_cores),
             "all_cores": {"value": all_cores, "unit": "triples/s", "cores": threads,
-                          "sample": "the same port on %d blocks of LUBM-10 side by side, one per thread" % threads}}
+                          "sample": "the same restatement on %d threads with one shared dictionary" % threads},
+            "query_geomean_ms": legs["strings_1_thread"]["geomean_ms"],
+            "query_legs": legs}
 
 
 def join_group(eng, args, rank, world, device):
@@ -338,7 +328,8 @@ def main():
     arr, n_triples = lubm.generate(u0, u1, seed=0, ontology=ontology, degree_pool=1000)
     text = torch.from_numpy(arr).to("cuda:%d" % local_rank)
     n_bytes = int(arr.size)
-    del arr
+    if world > 1 or args.no_cpu_baseline:
+        del arr   # the CPU baseline beside the single-GPU run works on the same bytes
     ci = lubm.class_index_text(args.partitions, ontology)
     torch.cuda.synchronize()
     eng = Engine(local_rank)
@@ -364,6 +355,8 @@ def main():
     qnames = sorted(queries, key=lambda n: int(n[1:-4]))
     plans = {n: parse_translated(queries[n]) for n in qnames}
 
+    load_rows = {}                                 # rows of the tables a statement reads (the reference's Load_data)
+
     def run_queries(first):
         times, counts, dev = {}, {}, {}
         for n in qnames:
@@ -373,9 +366,11 @@ def main():
                 eng.load_tables_sharded(parts)
                 shard.barrier(device)
             else:
+                rows = 0
                 for p in parts:                    # preloadTables: resident in HBM, reported as Time_load by the reference
-                    eng.load_table(p)              # (one call per table, as the reference loads them: the timed count that
+                    rows += eng.load_table(p)      # (one call per table, as the reference loads them: the timed count that
                                                    # follows a single batched load_tables call measures ~5 us longer)
+                load_rows[n] = rows
             if first and n == qnames[0]:
                 eng.query(sql, DX_QUERY_COUNT).close()   # the reference's one untimed run of the first query
             t0 = time.perf_counter()
@@ -489,6 +484,19 @@ def main():
                          "traffic": traffic},
             "kernel_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kernels.items()},
         }
+        if load_rows:
+            # Query path against the HBM roofline: algorithmic bytes of a counting statement = 16 B per row of every
+            # table it names (each (s, o) pair read once; nothing is written for a count), over the statement's device time
+            per = {n: {"bytes": 16 * load_rows[n], "device_ms": q_dev_med[n],
+                       "GBps": 16 * load_rows[n] / max(q_dev_med[n], 1e-9) / 1e6,
+                       "frac": 16 * load_rows[n] / max(q_dev_med[n], 1e-9) / 1e6 / HBM_PEAK_GBS} for n in qnames}
+            out["roofline_hp2"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "geomean_frac": math.exp(sum(math.log(max(v["frac"], 1e-12)) for v in per.values()) / len(per)),
+                                   "total_frac": sum(v["bytes"] for v in per.values()) / max(sum(v["device_ms"] for v in per.values()), 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                   "per_query": per,
+                                   "note": "device time between the events around a statement's kernels; the tables of these statements "
+                                           "hold 0.03-2.4 M rows, so a statement moves 1-40 MB: it is bound by the latency of its chain of "
+                                           "short kernels, not by bandwidth"}
         if measures is not None:
             out["instance_measures"] = {"device_ms": measures["device_ms"], "classes": measures["n_classes"],
                                         "cc_groups": measures["n_cc"], "cc_rows": measures["n_cc_rows"]}
@@ -498,7 +506,7 @@ def main():
             out["counts_equal_single_gpu"] = {"verified_on": "LUBM-%d partitioned and queried by all ranks together vs by rank 0 alone" % crosscheck[0],
                                               "counts": crosscheck[1]}
         if not args.no_cpu_baseline and world == 1:  # timed beside the single-GPU run only: the other ranks would wait for it
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(arr, n_triples, ci, args.partitions, plans, {n: int(counts[n]) for n in qnames})
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,6 +1,7 @@
 """ctypes front end of oracle/cpu_port.cpp (TEST INFRASTRUCTURE ONLY: checker and CPU baseline)."""
 import ctypes
 import os
+import re
 
 import numpy as np
 
@@ -21,6 +22,14 @@ def _lib():
         lib.cpu_port_rows_digest.restype = ctypes.c_uint64
         lib.cpu_port_rows_digest.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_uint64]
+        lib.cpu_port_run_mt.restype = ctypes.c_void_p
+        lib.cpu_port_run_mt.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_double)]
+        lib.cpu_port_table_rows.restype = ctypes.c_int64
+        lib.cpu_port_table_rows.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        lib.cpu_port_query.restype = ctypes.c_int64
+        lib.cpu_port_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         _LIB = lib
     return _LIB
 
@@ -49,10 +58,14 @@ def row_digest(s: str, o: str, p: str) -> int:
     return _mix(_fnv(e(s)) ^ _mix((_fnv(e(o)) + 0x9E3779B97F4A7C15) & M64) ^ _mix((_fnv(e(p)) + 0x632BE59BD9B4E019) & M64))
 
 
-def run(text_u8: np.ndarray, class_index_text: str, n_partitions: int) -> dict:
+def run(text_u8: np.ndarray, class_index_text: str, n_partitions: int, threads: int = 1) -> dict:
+    """threads > 1: the same restatement on that many threads with one shared dictionary (same statistics and digests)."""
     text_u8 = np.ascontiguousarray(text_u8, dtype=np.uint8)
     secs = ctypes.c_double(0)
-    h = _lib().cpu_port_run(text_u8.ctypes.data, text_u8.size, class_index_text.encode(), n_partitions, ctypes.byref(secs))
+    if threads > 1:
+        h = _lib().cpu_port_run_mt(text_u8.ctypes.data, text_u8.size, class_index_text.encode(), n_partitions, threads, 0, ctypes.byref(secs))
+    else:
+        h = _lib().cpu_port_run(text_u8.ctypes.data, text_u8.size, class_index_text.encode(), n_partitions, ctypes.byref(secs))
     out = np.zeros(6 + 2 * n_partitions, dtype=np.uint64)
     _lib().cpu_port_stats(h, out.ctypes.data)
     sizes = np.zeros(2, dtype=np.uint64)
@@ -86,3 +99,75 @@ def rows_digest(pool: np.ndarray, offs: np.ndarray, s: np.ndarray, o: np.ndarray
     s, o, p = (np.ascontiguousarray(a, dtype=np.int64) for a in (s, o, p))
     return int(_lib().cpu_port_rows_digest(pool.ctypes.data, offs.ctypes.data, offs.size - 1, s.ctypes.data, o.ctypes.data,
                                            p.ctypes.data, s.size))
+
+
+_SUB = re.compile(r"\(SELECT (.*?) FROM (\S+?)(?: WHERE (.*?))?\) AS (tab\d+)")
+_FILTER = re.compile(r"([so]) == '(.*?)'(?= AND [so] == '|$)")
+
+
+def parse_statement(sql: str, partitions):
+    """The sub-selects of a translated statement without UNION (QueryTranslator.scala:363-392, 417-455) as
+    (table key, s constant, o constant, s variable, o variable); equal variable names join."""
+    key_of = {"table" + p.replace("-", "_").replace("=", "_E_").strip(): p for p in partitions}
+    subs, var_no = [], {}
+    body = sql.split(" FROM ", 1)[1]
+    for proj, table, where, _alias in _SUB.findall(body):
+        s_var = o_var = -1
+        for item in proj.split(","):
+            col, name = item.strip().split(" AS ")
+            no = var_no.setdefault(name.strip(), len(var_no))
+            if col.strip() == "s":
+                s_var = no
+            elif col.strip() == "o":
+                o_var = no
+            else:
+                raise ValueError("projected constant: not a plain basic graph pattern")
+        consts = dict(_FILTER.findall(where)) if where else {}
+        subs.append((key_of[table], consts.get("s"), consts.get("o"), s_var, o_var))
+    if "UNION" in sql or not subs:
+        raise ValueError("statement outside the subset the CPU query leg runs")
+    return subs
+
+
+class Dataset:
+    """A partitioning kept for queries: the vertical-partition tables of cpu_port.cpp over the given text."""
+
+    def __init__(self, text_u8: np.ndarray, class_index_text: str, n_partitions: int, threads: int = 1):
+        self._text = np.ascontiguousarray(text_u8, dtype=np.uint8)  # the tables' strings point into it
+        secs = ctypes.c_double(0)
+        self._h = _lib().cpu_port_run_mt(self._text.ctypes.data, self._text.size, class_index_text.encode(), n_partitions, threads, 1,
+                                         ctypes.byref(secs))
+        self.seconds = secs.value
+        out = np.zeros(6 + 2 * n_partitions, dtype=np.uint64)
+        _lib().cpu_port_stats(self._h, out.ctypes.data)
+        if out[0]:
+            self.close()
+            raise ValueError("malformed N-Triples input")
+        self.n_triples = int(out[1])
+
+    def table_rows(self, key: str) -> int:
+        return int(_lib().cpu_port_table_rows(self._h, key.encode("utf-8", "surrogateescape")))
+
+    def count(self, sql: str, partitions, threads: int = 1, string_keyed: bool = False):
+        """(count, seconds) of the statement: scans with constant filters, hash joins on the shared variables, count."""
+        subs = parse_statement(sql, partitions)
+        n = len(subs)
+        enc = lambda x: None if x is None else x.encode("utf-8", "surrogateescape")  # noqa: E731
+        tables = (ctypes.c_char_p * n)(*[enc(s[0]) for s in subs])
+        sc = (ctypes.c_char_p * n)(*[enc(s[1]) for s in subs])
+        oc = (ctypes.c_char_p * n)(*[enc(s[2]) for s in subs])
+        sv = (ctypes.c_int * n)(*[s[3] for s in subs])
+        ov = (ctypes.c_int * n)(*[s[4] for s in subs])
+        secs = ctypes.c_double(0)
+        c = _lib().cpu_port_query(self._h, n, tables, sc, oc, sv, ov, threads, 1 if string_keyed else 0, ctypes.byref(secs))
+        if c < 0:
+            raise KeyError("statement names a table the partitioning does not have")
+        return int(c), secs.value
+
+    def close(self):
+        if self._h:
+            _lib().cpu_port_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

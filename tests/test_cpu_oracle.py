@@ -219,3 +219,38 @@ def test_instance_measures_cpp_restatement_agrees_with_python():
                for c in set(ref["schema_node_count"]) | set(ref["schema_node_freq"])}
     assert classes == got["classes"] and len(classes) > 10
     assert {(H(a), H(b), H(c)): v for (a, b, c), v in ref["schema_cc"].items()} == got["cc"]
+
+
+def test_cpu_port_on_threads_equals_one_thread_and_answers_like_sqlite(lubm1):
+    """The restatement on several threads (one shared dictionary) gives the statistics and digests of the
+    single-threaded one, keeps the same vertical-partition tables as the string-level oracle, and its query leg
+    (scans + hash joins, keyed on ids or on strings, one thread or several) counts what SQLite counts."""
+    import numpy as np
+    from opus_amd import lubm
+    from opus_amd.host import translator as T
+    from oracle import cpu_port, query_oracle
+    arr, ci, ref = lubm1["bytes"], lubm1["class_index"], lubm1["oracle"]
+    one = cpu_port.run(arr, ci, 4)
+    for threads in (2, 5):
+        many = cpu_port.run(arr, ci, 4, threads=threads)
+        assert {k: v for k, v in many.items() if k not in ("seconds", "measures")} == \
+               {k: v for k, v in one.items() if k not in ("seconds", "measures")}
+    ds = cpu_port.Dataset(arr, ci, 4, threads=3)
+    try:
+        for (part, sub), rows in ref["vp"].items():
+            assert ds.table_rows(part + "-" + sub) == len(rows)
+        assert ds.table_rows("00000-_3=_no_such_table_") == -1
+        ni = {}
+        for u, c in ref["node_index"]:
+            ni.setdefault(u, []).append(c)
+        cidx = T.load_class_index(ci)
+        for name, text in lubm.queries(0).items():
+            tr = T.translate_query(name, text, lambda x: ni.get(x, []), cidx, ref["partition_stat"])
+            qm, parts, _ = query_oracle.parse_translated_file(tr)
+            want = query_oracle.run_query(ref["vp"], tr)["count"]
+            sql = next(iter(qm.values()))
+            for threads in (1, 3):
+                for by_string in (False, True):
+                    assert ds.count(sql, parts, threads=threads, string_keyed=by_string)[0] == want, (name, threads, by_string)
+    finally:
+        ds.close()
