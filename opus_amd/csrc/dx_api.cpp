@@ -4,8 +4,11 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <ctime>
 #include <fstream>
+#include <map>
 #include <sstream>
+#include <unordered_map>
 
 #include "dx_device.h"
 #include "dx_state.h"
@@ -216,6 +219,10 @@ void dx_free(dx_ctx* ctx) {
   if (ctx->q_ev0) { (void)hipEventDestroy(ctx->q_ev0); (void)hipEventDestroy(ctx->q_ev1); }
   if (ctx->q_host) (void)hipHostFree(ctx->q_host);
   if (ctx->q_counters) (void)hipFree(ctx->q_counters);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->file_stage[b]) (void)hipHostFree(ctx->file_stage[b]);
+    if (ctx->file_stage_ev[b]) (void)hipEventDestroy(ctx->file_stage_ev[b]);
+  }
   if (ctx->part_host) (void)hipHostFree(ctx->part_host);
   for (hipEvent_t e : ctx->part_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
@@ -247,23 +254,29 @@ int dx_partition_file(dx_ctx* ctx, const char* instances_path, const char* class
     const uint64_t n = (uint64_t)f.tellg();
     f.seekg(0);
     DevBuf<uint8_t> text(ctx->pool, n + 16);
-    // stream through a pinned staging buffer: the file never has to fit in host memory
+    // Streamed through two pinned staging buffers (kept by the context): the file never has to fit in host memory,
+    // and while one buffer's copy to the device is in flight the next piece of the file is read into the other.
     const size_t chunk = 64u << 20;
-    void* stage = nullptr;
-    DX_HIP(hipHostMalloc(&stage, chunk, hipHostMallocDefault));
-    try {
-      for (uint64_t done = 0; done < n;) {
-        const size_t want = (size_t)std::min<uint64_t>(chunk, n - done);
-        f.read((char*)stage, (std::streamsize)want);
-        if ((size_t)f.gcount() != want) throw DxError(DX_E_IO, std::string("short read on ") + instances_path);
-        DX_HIP(hipMemcpy(text.p + done, stage, want, hipMemcpyHostToDevice));
-        done += want;
-      }
-    } catch (...) {
-      (void)hipHostFree(stage);
-      throw;
+    for (int b = 0; b < 2; ++b) {
+      if (!ctx->file_stage[b]) DX_HIP(hipHostMalloc(&ctx->file_stage[b], chunk, hipHostMallocDefault));
+      if (!ctx->file_stage_ev[b]) DX_HIP(hipEventCreateWithFlags(&ctx->file_stage_ev[b], hipEventDisableTiming));
     }
-    (void)hipHostFree(stage);
+    bool in_flight[2] = {false, false};
+    int b = 0;
+    for (uint64_t done = 0; done < n; b ^= 1) {
+      const size_t want = (size_t)std::min<uint64_t>(chunk, n - done);
+      if (in_flight[b]) { DX_HIP(hipEventSynchronize(ctx->file_stage_ev[b])); in_flight[b] = false; }
+      f.read((char*)ctx->file_stage[b], (std::streamsize)want);
+      if ((size_t)f.gcount() != want) {
+        (void)hipStreamSynchronize(ctx->stream);  // the other buffer's copy may still be running
+        throw DxError(DX_E_IO, std::string("short read on ") + instances_path);
+      }
+      DX_HIP(hipMemcpyAsync(text.p + done, ctx->file_stage[b], want, hipMemcpyHostToDevice, ctx->stream));
+      DX_HIP(hipEventRecord(ctx->file_stage_ev[b], ctx->stream));
+      in_flight[b] = true;
+      done += want;
+    }
+    DX_HIP(hipStreamSynchronize(ctx->stream));
     const auto classes = parse_class_index(ci, n_partitions);
     run_partition(ctx, text.p, n, classes, n_partitions);
     if (stats) *stats = ctx->part.stats;
@@ -569,19 +582,29 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
     if (stat(clusters.c_str(), &stt) == 0)  // DAP.scala:86: the stage is skipped when its output exists
       throw DxError(DX_E_INVAL, clusters + " already exists (the reference skips the stage in that case; remove it to rewrite)");
     mkdirs(clusters);
-    // dictionary
-    const std::string dd = B + D + "_data/dx_dictionary";
+    // What the Scala tools read is written as Parquet where they look for it. Beside it, under <dataset>_data/dx_<N>/
+    // (a directory none of them lists), the dictionary and the tables' id columns, which dx_open_dataset and
+    // dx_load_table read back without decoding strings.
+    const std::string side = B + D + "_data/dx_" + N;
+    const std::string dd = side + "/dictionary";
     mkdirs(dd);
+    std::vector<uint64_t> off(d.n_terms + 1);
+    std::vector<uint8_t> pool;
     {
-      std::vector<uint64_t> off(d.n_terms + 1);
       fetch(off.data(), d.pool_off.p, off.size() * 8);
-      std::vector<uint8_t> pool(off[d.n_terms]);
+      pool.resize(off[d.n_terms]);
       fetch(pool.data(), d.pool.p, pool.size());
       std::ofstream f1(dd + "/offsets.bin", std::ios::binary), f2(dd + "/terms.bin", std::ios::binary);
       f1.write((const char*)off.data(), (std::streamsize)(off.size() * 8));
       f2.write((const char*)pool.data(), (std::streamsize)pool.size());
       if (!f1 || !f2) throw DxError(DX_E_IO, "writing dictionary failed");
     }
+    const uint64_t nt = d.n_terms;
+    // Spark names its files part-<task>-<job uuid>-c000.<codec>.parquet; the partition number is read from the five
+    // digits after "part-" (DAP.scala:427-428). One id per call stands in for the job's uuid.
+    char job[64];
+    snprintf(job, sizeof job, "%08x-dx00-4000-8000-%012llx", (unsigned)time(nullptr), (unsigned long long)(uintptr_t)ctx & 0xFFFFFFFFFFFFull);
+    auto part_file = [&](int k) { return "part-" + part_name(k) + "-" + job + "-c000.parquet"; };
     // first-level partitions + statistics.txt_N (DAP.scala:364-381)
     mkdirs(L + D + "_local");
     std::ofstream stats(L + D + "_local/statistics.txt_" + N);
@@ -595,7 +618,9 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
       std::vector<uint32_t> pi(n);
       fetch(pi.data(), ps.row_p.p + ps.part_base[q], n * 4);
       for (uint64_t i = 0; i < n; ++i) hp[i] = ps.pred_terms[pi[i]];
-      write_cols(clusters + "/part-" + part_name(q) + "-dx-c000.dxcol", n, {hs.data(), ho.data(), hp.data()});
+      ParquetWriter w(clusters + "/" + part_file(q), {"_1", "_2", "_3"});  // (s, o, p): DAP.scala:576,592,628
+      w.append(n, {{hs.data(), nullptr}, {ho.data(), nullptr}, {hp.data(), nullptr}}, pool.data(), off.data(), nt);
+      w.close();
       const std::string qs = std::to_string(q);
       stats << (qs.size() == 1 ? "0" + qs : qs) << " " << n << "\n";
     }
@@ -605,14 +630,19 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
     std::map<std::string, int> file_no;
     for (const VpTable& t : ps.tables) {
       if (!t.in_layout) continue;
+      const std::string rel = part_name(t.partition) + "/_3=" + ps.pred_storage[t.pidx];
       const std::string pdir = clusters + "/" + part_name(t.partition);
-      const std::string dir = pdir + "/_3=" + ps.pred_storage[t.pidx];
+      const std::string dir = clusters + "/" + rel, sdir = side + "/cluster/" + rel;
       mkdirs(dir);
+      mkdirs(sdir);
       hs.resize(t.rows); ho.resize(t.rows);
       fetch(hs.data(), ps.row_s.p + t.begin, t.rows * 8);
       fetch(ho.data(), ps.row_o.p + t.begin, t.rows * 8);
       const int k = file_no[dir]++;
-      write_cols(dir + "/part-" + part_name(k) + "-dx.c000.dxcol", t.rows, {hs.data(), ho.data()});
+      ParquetWriter w(dir + "/" + part_file(k), {"_1", "_2"});
+      w.append(t.rows, {{hs.data(), nullptr}, {ho.data(), nullptr}}, pool.data(), off.data(), nt);
+      w.close();
+      write_cols(sdir + "/part-" + part_name(k) + ".dxcol", t.rows, {hs.data(), ho.data()});
       dir_rows[part_name(t.partition)] += t.rows;
       touch(pdir + "/_SUCCESS");
     }
@@ -621,7 +651,7 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
       for (auto& kv : dir_rows) pstat << kv.first << " " << kv.second << "\n";  // `hdfs dfs -ls` lists by name
       for (int q = 0; q < ps.n_partitions; ++q) {
         const uint64_t n = ps.part_base[q + 1] - ps.part_base[q];
-        if (n) pstat << "part-" << part_name(q) << "-dx-c000.dxcol " << n << "\n";
+        if (n) pstat << part_file(q) << " " << n << "\n";
       }
     }
     // statTables.txt: rows per VP table, the input QueryOptimizer.scala:270-276 reads (the reference has no writer for it)
@@ -632,30 +662,57 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
         if (t.in_layout) rows[part_name(t.partition) + "-_3=" + ps.pred_storage[t.pidx]] += t.rows;
       for (auto& kv : rows) st << kv.first << " " << kv.second << "\n";
     }
-    // node index (DAP.scala:402-412)
+    // node index (DAP.scala:402-412): Types.NodeIndex(uri, uriType)
     {
       const std::string ni = B + D + "_data/node_index_" + N;
       mkdirs(ni);
       hs.resize(ps.n_node); ho.resize(ps.n_node);
       fetch(hs.data(), ps.node_s.p, ps.n_node * 8);
       fetch(ho.data(), ps.node_o.p, ps.n_node * 8);
-      write_cols(ni + "/part-00000-dx.c000.dxcol", ps.n_node, {hs.data(), ho.data()});
+      ParquetWriter w(ni + "/" + part_file(0), {"uri", "uriType"});
+      w.append(ps.n_node, {{hs.data(), nullptr}, {ho.data(), nullptr}}, pool.data(), off.data(), nt);
+      w.close();
       touch(ni + "/_SUCCESS");
     }
-    // VP index (DAP.scala:450-501)
+    // VP index (DAP.scala:450-501): one row per uri with the set of "s" / "o" + sanitised predicate it occurs with,
+    // joined by commas (collect_set leaves the order open: sorted here)
     for (int q = 0; q < ps.n_partitions; ++q) {
       if (ps.part_base[q + 1] == ps.part_base[q]) continue;
       const uint64_t n = (uint64_t)dx_vp_index_rows(ctx, q);
-      std::vector<int64_t> u(n), pr(n), rl(n);
+      std::vector<int64_t> u(n), pr(n);
       std::vector<int32_t> r32(n);
       if (n) {
         int rc = dx_vp_index_fetch(ctx, q, u.data(), r32.data(), pr.data());
         if (rc) throw DxError(rc, ctx->err);
       }
-      for (uint64_t i = 0; i < n; ++i) rl[i] = r32[i];
+      std::unordered_map<int64_t, std::string> storage;  // predicate term -> sanitised name
+      for (uint32_t i = 0; i < ps.pred_terms.size(); ++i) storage[ps.pred_terms[i]] = ps.pred_storage[i];
+      std::vector<uint64_t> order(n);
+      for (uint64_t i = 0; i < n; ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return u[a] < u[b]; });
+      std::vector<int64_t> uris;
+      std::vector<std::string> parts;
+      for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        std::vector<std::string> set;
+        for (; j < n && u[order[j]] == u[order[i]]; ++j) {
+          auto it = storage.find(pr[order[j]]);
+          if (it == storage.end()) throw DxError(DX_E_INVAL, "VP index names a predicate the partition run does not know");
+          set.push_back((r32[order[j]] == 0 ? "s" : "o") + it->second);
+        }
+        std::sort(set.begin(), set.end());
+        set.erase(std::unique(set.begin(), set.end()), set.end());
+        std::string joined;
+        for (size_t k = 0; k < set.size(); ++k) joined += (k ? "," : "") + set[k];
+        uris.push_back(u[order[i]]);
+        parts.push_back(std::move(joined));
+        i = j;
+      }
       const std::string dir = B + D + "_data/classSubPart_index_" + N + "__" + part_name(q);
       mkdirs(dir);
-      write_cols(dir + "/part-00000-dx.c000.dxcol", n, {u.data(), rl.data(), pr.data()});
+      ParquetWriter w(dir + "/" + part_file(0), {"uri", "parts"});
+      w.append(uris.size(), {{uris.data(), nullptr}, {nullptr, parts.data()}}, pool.data(), off.data(), nt);
+      w.close();
       touch(dir + "/_SUCCESS");
     }
   });
@@ -665,7 +722,11 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
   return guard(ctx, [&] {
     if (!dataset) throw DxError(DX_E_INVAL, "null dataset");
     const std::string B = norm_base(base), D = dataset;
-    const std::string dd = B + D + "_data/dx_dictionary";
+    const std::string dd = B + D + "_data/dx_" + std::to_string(n_partitions) + "/dictionary";
+    struct stat sdd;
+    if (stat(dd.c_str(), &sdd) != 0)
+      throw DxError(DX_E_NOENT, dd + " not found: a layout written by dx_part_write_layout carries its dictionary and id columns there; "
+                                     "tables written by the Scala tools are loaded with dx_dictionary_load + dx_load_table_ids");
     const std::string offs = read_file(dd + "/offsets.bin"), terms = read_file(dd + "/terms.bin");
     if (offs.size() < 8 || offs.size() % 8) throw DxError(DX_E_IO, "corrupt dictionary offsets");
     {  // the kernels index the term pool by these: they must start at 0, never decrease and end at the pool's size
@@ -700,7 +761,7 @@ static void load_from_disk(dx_ctx* ctx, const std::string& key, CatalogTable& t)
   std::string rel = key;
   const size_t dash = key.find('-');
   if (dash != std::string::npos) rel = key.substr(0, dash) + "/" + key.substr(dash + 1);
-  const std::string dir = ctx->ds_base + ctx->ds_name + "_data/cluster/clusters_" + std::to_string(ctx->ds_partitions) + "_bal/" + rel;
+  const std::string dir = ctx->ds_base + ctx->ds_name + "_data/dx_" + std::to_string(ctx->ds_partitions) + "/cluster/" + rel;  // the id columns beside it
   DIR* dp = opendir(dir.c_str());
   if (!dp) throw DxError(DX_E_NOENT, "cannot open " + dir);
   std::vector<std::string> files;

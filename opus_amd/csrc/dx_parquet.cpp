@@ -1,0 +1,261 @@
+// A minimal Parquet writer for the reference's on-disk layout (host code, no GPU work).
+//
+// Everything the Scala tools write with DataFrame.write.parquet is a flat table of string columns
+// (partitioner/DAP.scala:364-367 `_1,_2,_3`; :433-437 `_1,_2`; :405-412 `uri,uriType`; :496-499 `uri,parts`;
+// case classes in utils/Types.scala:7-16). This writer produces such files so that spark.read.load (Loader.scala:19-38,
+// QueryProcessor.scala:308-339) and any other Parquet reader accept them: format version 1, one row group per
+// kRowGroupRows rows, REQUIRED BYTE_ARRAY columns annotated UTF8, per column chunk one dictionary page (PLAIN) and
+// one data page of bit-packed dictionary indices (the PLAIN_DICTIONARY encoding of parquet-mr's first-version
+// pages), no compression, Thrift compact footer. Terms repeat heavily inside a column, so the dictionary pages keep
+// the files near the size of Spark's own (which adds snappy on top).
+#include <cstdio>
+#include <cstring>
+
+#include "dx_state.h"
+
+namespace dx {
+namespace {
+
+// ---- Thrift compact protocol, as much of it as the footer and the page headers need ----------------------
+struct Thrift {
+  std::string out;
+  std::vector<int> last;  // last field id of every open struct
+  Thrift() { last.push_back(0); }
+  void varint(uint64_t v) {
+    while (v >= 0x80) { out.push_back((char)(v | 0x80)); v >>= 7; }
+    out.push_back((char)v);
+  }
+  static uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+  void field(int id, int type) {
+    const int delta = id - last.back();
+    if (delta > 0 && delta <= 15) out.push_back((char)((delta << 4) | type));
+    else { out.push_back((char)type); varint(zigzag(id)); }
+    last.back() = id;
+  }
+  void i32(int id, int32_t v) { field(id, 5); varint(zigzag(v)); }
+  void i64(int id, int64_t v) { field(id, 6); varint(zigzag(v)); }
+  void str(int id, const std::string& s) { field(id, 8); varint(s.size()); out += s; }
+  void begin_struct(int id) { field(id, 12); last.push_back(0); }
+  void end_struct() { out.push_back(0); last.pop_back(); }
+  void list(int id, int elem_type, size_t n) {
+    field(id, 9);
+    if (n < 15) out.push_back((char)((n << 4) | elem_type));
+    else { out.push_back((char)(0xF0 | elem_type)); varint(n); }
+  }
+  // list elements carry no field header
+  void elem_struct_begin() { last.push_back(0); }
+  void elem_i32(int32_t v) { varint(zigzag(v)); }
+  void elem_str(const std::string& s) { varint(s.size()); out += s; }
+};
+
+constexpr int kByteArray = 6, kRequired = 0, kUtf8 = 0, kPlain = 0, kPlainDictionary = 2, kRle = 3, kUncompressed = 0;
+constexpr int kDataPage = 0, kDictionaryPage = 2;
+constexpr uint64_t kRowGroupRows = 1u << 20;
+
+struct ChunkMeta {
+  int64_t dict_offset, data_offset, total_size, num_values;
+};
+
+void put_u32(std::string& s, uint32_t v) { s.append(reinterpret_cast<const char*>(&v), 4); }
+
+std::string page_header(int type, size_t size, uint64_t num_values, bool dictionary_encoded) {
+  Thrift t;
+  t.i32(1, type);
+  t.i32(2, (int32_t)size);
+  t.i32(3, (int32_t)size);
+  if (type == kDataPage) {
+    t.begin_struct(5);
+    t.i32(1, (int32_t)num_values);
+    t.i32(2, dictionary_encoded ? kPlainDictionary : kPlain);
+    t.i32(3, kRle);
+    t.i32(4, kRle);
+    t.end_struct();
+  } else {
+    t.begin_struct(7);
+    t.i32(1, (int32_t)num_values);
+    t.i32(2, kPlainDictionary);
+    t.end_struct();
+  }
+  t.out.push_back(0);  // end of PageHeader
+  return t.out;
+}
+
+}  // namespace
+
+struct ParquetWriter::Impl {
+  FILE* f = nullptr;
+  std::string path;
+  std::vector<std::string> names;
+  uint64_t at = 0, rows = 0;
+  struct Group { uint64_t rows; std::vector<ChunkMeta> cols; };
+  std::vector<Group> groups;
+  // id -> index in the current chunk's dictionary, valid where stamp[id] == epoch
+  std::vector<uint32_t> local, stamp;
+  uint32_t epoch = 0;
+  void write(const std::string& s) {
+    if (s.empty()) return;
+    if (fwrite(s.data(), 1, s.size(), f) != s.size()) throw DxError(DX_E_IO, "write failed: " + path);
+    at += s.size();
+  }
+};
+
+ParquetWriter::ParquetWriter(const std::string& path, const std::vector<std::string>& column_names) : p(new Impl) {
+  p->path = path;
+  p->names = column_names;
+  p->f = fopen(path.c_str(), "wb");
+  if (!p->f) { delete p; p = nullptr; throw DxError(DX_E_IO, "cannot create " + path); }
+  p->write("PAR1");
+}
+
+ParquetWriter::~ParquetWriter() {
+  if (p) {
+    if (p->f) fclose(p->f);
+    delete p;
+  }
+}
+
+// One chunk of a column whose values are given as term ids: dictionary page over the ids that occur, then indices.
+static ChunkMeta write_id_chunk(ParquetWriter::Impl* p, const int64_t* ids, uint64_t n, const uint8_t* pool, const uint64_t* pool_off,
+                                uint64_t n_terms) {
+  if (p->local.size() < n_terms) { p->local.assign(n_terms, 0); p->stamp.assign(n_terms, 0); p->epoch = 0; }
+  if (++p->epoch == 0) { std::fill(p->stamp.begin(), p->stamp.end(), 0); p->epoch = 1; }
+  std::string dict;
+  std::vector<uint32_t> idx(n);
+  uint32_t n_dict = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t id = (uint64_t)ids[i];
+    if (id >= n_terms) throw DxError(DX_E_RANGE, "term id outside the dictionary while writing " + p->path);
+    if (p->stamp[id] != p->epoch) {
+      p->stamp[id] = p->epoch;
+      p->local[id] = n_dict++;
+      const uint64_t b = pool_off[id], len = pool_off[id + 1] - b;
+      put_u32(dict, (uint32_t)len);
+      dict.append(reinterpret_cast<const char*>(pool + b), len);
+    }
+    idx[i] = p->local[id];
+  }
+  if (dict.size() >= (1ull << 31)) throw DxError(DX_E_RANGE, "dictionary page of 2 GiB or more in " + p->path);
+  int width = 0;
+  while ((1ull << width) < n_dict) ++width;
+  // data page: bit width, then one bit-packed run of ceil(n / 8) groups of eight values, least significant bit first
+  const uint64_t groups = (n + 7) / 8;
+  std::string data;
+  data.push_back((char)width);
+  {
+    Thrift v;
+    v.varint((groups << 1) | 1);
+    data += v.out;
+  }
+  const size_t base = data.size();
+  data.resize(base + groups * (uint64_t)width, 0);
+  if (width) {
+    uint8_t* d = reinterpret_cast<uint8_t*>(&data[base]);
+    uint64_t bit = 0;
+    for (uint64_t i = 0; i < n; ++i, bit += width) {
+      const uint64_t v = idx[i];
+      uint64_t byte = bit >> 3;
+      const int sh = (int)(bit & 7);
+      uint64_t word = v << sh;  // width <= 32, sh <= 7: fits
+      for (int k = 0; k < 5 && word; ++k, word >>= 8) d[byte + k] |= (uint8_t)word;
+    }
+  }
+  ChunkMeta m{};
+  m.num_values = (int64_t)n;
+  m.dict_offset = (int64_t)p->at;
+  const std::string dh = page_header(kDictionaryPage, dict.size(), n_dict, true);
+  p->write(dh);
+  p->write(dict);
+  m.data_offset = (int64_t)p->at;
+  const std::string ph = page_header(kDataPage, data.size(), n, true);
+  p->write(ph);
+  p->write(data);
+  m.total_size = (int64_t)p->at - m.dict_offset;
+  return m;
+}
+
+// One chunk of a column given as strings: a PLAIN data page.
+static ChunkMeta write_string_chunk(ParquetWriter::Impl* p, const std::string* vals, uint64_t n) {
+  std::string data;
+  for (uint64_t i = 0; i < n; ++i) { put_u32(data, (uint32_t)vals[i].size()); data += vals[i]; }
+  if (data.size() >= (1ull << 31)) throw DxError(DX_E_RANGE, "data page of 2 GiB or more in " + p->path);
+  ChunkMeta m{};
+  m.num_values = (int64_t)n;
+  m.dict_offset = -1;
+  m.data_offset = (int64_t)p->at;
+  p->write(page_header(kDataPage, data.size(), n, false));
+  p->write(data);
+  m.total_size = (int64_t)p->at - m.data_offset;
+  return m;
+}
+
+void ParquetWriter::append(uint64_t n, const std::vector<Column>& cols, const uint8_t* pool, const uint64_t* pool_off, uint64_t n_terms) {
+  if (cols.size() != p->names.size()) throw DxError(DX_E_INVAL, "parquet: column count differs from the schema");
+  for (uint64_t b = 0; b < n; b += kRowGroupRows) {
+    const uint64_t m = std::min<uint64_t>(kRowGroupRows, n - b);
+    Impl::Group g;
+    g.rows = m;
+    for (const Column& c : cols)
+      g.cols.push_back(c.ids ? write_id_chunk(p, c.ids + b, m, pool, pool_off, n_terms) : write_string_chunk(p, c.strings + b, m));
+    p->groups.push_back(std::move(g));
+  }
+  p->rows += n;
+}
+
+void ParquetWriter::close() {
+  Thrift t;
+  t.i32(1, 1);  // version
+  t.list(2, 12, p->names.size() + 1);
+  t.elem_struct_begin();  // root
+  t.str(4, "spark_schema");
+  t.i32(5, (int32_t)p->names.size());
+  t.end_struct();
+  for (const std::string& nm : p->names) {
+    t.elem_struct_begin();
+    t.i32(1, kByteArray);
+    t.i32(3, kRequired);
+    t.str(4, nm);
+    t.i32(6, kUtf8);
+    t.end_struct();
+  }
+  t.i64(3, (int64_t)p->rows);
+  t.list(4, 12, p->groups.size());
+  for (const auto& g : p->groups) {
+    t.elem_struct_begin();
+    t.list(1, 12, g.cols.size());
+    int64_t total = 0;
+    for (size_t c = 0; c < g.cols.size(); ++c) {
+      const ChunkMeta& m = g.cols[c];
+      total += m.total_size;
+      t.elem_struct_begin();  // ColumnChunk
+      t.i64(2, m.dict_offset >= 0 ? m.dict_offset : m.data_offset);
+      t.begin_struct(3);      // ColumnMetaData
+      t.i32(1, kByteArray);
+      if (m.dict_offset >= 0) { t.list(2, 5, 2); t.elem_i32(kPlainDictionary); t.elem_i32(kRle); }
+      else { t.list(2, 5, 2); t.elem_i32(kPlain); t.elem_i32(kRle); }
+      t.list(3, 8, 1);
+      t.elem_str(p->names[c]);
+      t.i32(4, kUncompressed);
+      t.i64(5, m.num_values);
+      t.i64(6, m.total_size);
+      t.i64(7, m.total_size);
+      t.i64(9, m.data_offset);
+      if (m.dict_offset >= 0) t.i64(11, m.dict_offset);
+      t.end_struct();
+      t.end_struct();
+    }
+    t.i64(2, total);
+    t.i64(3, (int64_t)g.rows);
+    t.end_struct();
+  }
+  t.str(6, "diaeresis-hip (parquet format 1, plain dictionary pages, uncompressed)");
+  t.out.push_back(0);
+  p->write(t.out);
+  std::string tail;
+  put_u32(tail, (uint32_t)t.out.size());
+  tail += "PAR1";
+  p->write(tail);
+  if (fclose(p->f) != 0) { p->f = nullptr; throw DxError(DX_E_IO, "close failed: " + p->path); }
+  p->f = nullptr;
+}
+
+}  // namespace dx

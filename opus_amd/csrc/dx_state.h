@@ -132,6 +132,8 @@ struct dx_ctx {
   void* q_host = nullptr;               // pinned block the final counters of a statement land in
   void* q_host_dev = nullptr;           // the same block as the device addresses it
   uint64_t q_seq = 0;                   // statements run on this context so far
+  void* file_stage[2] = {nullptr, nullptr};        // pinned buffers dx_partition_file streams a file through
+  hipEvent_t file_stage_ev[2] = {nullptr, nullptr};
   void* q_counters = nullptr;           // device: a statement's row counters and its last-block ticket, zero between statements
   std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
   bool q_counters_dirty = false;        // a statement failed between its first and its last kernel: clear before the next
@@ -220,6 +222,24 @@ struct dx_result {
 };
 
 namespace dx {
+// dx_parquet.cpp: files of REQUIRED string columns as the reference's Spark jobs write them (schemas of
+// utils/Types.scala:7-16). A column is given as term ids over a string pool, or as strings.
+class ParquetWriter {
+ public:
+  struct Column { const int64_t* ids; const std::string* strings; };
+  struct Impl;
+  ParquetWriter(const std::string& path, const std::vector<std::string>& column_names);
+  ~ParquetWriter();
+  ParquetWriter(const ParquetWriter&) = delete;
+  ParquetWriter& operator=(const ParquetWriter&) = delete;
+  // n more rows; pool / pool_off / n_terms describe the strings behind the id columns
+  void append(uint64_t n, const std::vector<Column>& cols, const uint8_t* pool, const uint64_t* pool_off, uint64_t n_terms);
+  void close();  // footer; the destructor only releases the file
+
+ private:
+  Impl* p;
+};
+
 // dx_hp1.hip
 void run_partition(dx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
                    int n_partitions);

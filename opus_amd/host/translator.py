@@ -405,80 +405,27 @@ def load_partition_stats(text: str) -> dict:
 
 
 # ---- command line: the stand-in behind scripts/run_translator.sh ------------------------------------------
-def _read_dxcol(path: str):
-    """Column file written by dx_part_write_layout: 8-byte magic, rows, columns, then int64 columns."""
-    import numpy as np
-    with open(path, "rb") as f:
-        head = f.read(24)
-        if head[:6] != b"DXCOL1":
-            raise ValueError("not a column file: " + path)
-        rows, ncols = np.frombuffer(head[8:], dtype=np.uint64)
-        data = np.fromfile(f, dtype=np.int64, count=int(rows) * int(ncols))
-    return data.reshape(int(ncols), int(rows))
-
-
 def load_layout_indexes(base: str, dataset: str, n: int):
-    """node_types(uri) and sub_parts(partition, uri) over a layout on disk: the Parquet files of the Scala tools
-    (Loader.loadNodeIndex / loadSubPartIndex) where they exist, else the column files of dx_part_write_layout
-    with its dictionary directory."""
-    import glob
+    """node_types(uri) and sub_parts(partition, uri) over a layout on disk: the Parquet files
+    Loader.loadNodeIndex / loadSubPartIndex read (Loader.scala:266-276), whoever wrote them -- the Scala tools,
+    dx_part_write_layout or parquet_io.export_layout."""
     import os
 
-    import numpy as np
+    from . import parquet_io
     data_dir = os.path.join(base, dataset + "_data")
-    ni_dir = os.path.join(data_dir, "node_index_%d" % n)
     node = {}
-    if glob.glob(os.path.join(ni_dir, "*.parquet")):
-        from . import parquet_io
-        t = parquet_io.read_table(ni_dir)
-        for u, c in zip(t.column("uri").to_pylist(), t.column("uriType").to_pylist()):
-            node.setdefault(u, []).append(c)
-        sub_cache = {}
-
-        def sub_parts(part, uri):
-            if part not in sub_cache:
-                d = os.path.join(data_dir, "classSubPart_index_%d__%s" % (n, part))
-                tt = parquet_io.read_table(d)
-                sub_cache[part] = dict(zip(tt.column("uri").to_pylist(), tt.column("parts").to_pylist()))
-            return [x for x in sub_cache[part].get(uri, "").split(",") if x]
-        return (lambda uri: node.get(uri, [])), sub_parts
-    offs = np.fromfile(os.path.join(data_dir, "dx_dictionary", "offsets.bin"), dtype=np.uint64).astype(np.int64)
-    terms = np.fromfile(os.path.join(data_dir, "dx_dictionary", "terms.bin"), dtype=np.uint8)
-    lengths = np.diff(offs)
-    ids = {}
-
-    def term(i):
-        return bytes(terms[offs[i]:offs[i + 1]]).decode("utf-8", "surrogateescape")
-
-    def term_id(uri):
-        """Id of a term string, -1 if the dictionary does not hold it (a scan over the terms of its length)."""
-        if uri not in ids:
-            want = uri.encode("utf-8", "surrogateescape")
-            ids[uri] = -1
-            for k in np.flatnonzero(lengths == len(want)).tolist():
-                if bytes(terms[offs[k]:offs[k + 1]]) == want:
-                    ids[uri] = k
-                    break
-        return ids[uri]
-    u, c = _read_dxcol(glob.glob(os.path.join(ni_dir, "*.dxcol"))[0])
-    cls = {k: term(k) for k in np.unique(c).tolist()}
-    for a, b in zip(u.tolist(), c.tolist()):
-        node.setdefault(a, []).append(cls[b])
+    t = parquet_io.read_table(os.path.join(data_dir, "node_index_%d" % n))
+    for u, c in zip(t.column("uri").to_pylist(), t.column("uriType").to_pylist()):
+        node.setdefault(u, []).append(c)
     sub_cache = {}
 
     def sub_parts(part, uri):
         if part not in sub_cache:
-            files = glob.glob(os.path.join(data_dir, "classSubPart_index_%d__%s" % (n, part), "*.dxcol"))
-            sub_cache[part] = _read_dxcol(files[0]) if files else np.zeros((3, 0), dtype=np.int64)
-        uu, role, pred = sub_cache[part]
-        sel = uu == term_id(uri)
-        out = []
-        for r, p in zip(role[sel].tolist(), pred[sel].tolist()):
-            e = ("s" if r == 0 else "o") + uri_to_storage(term(p))
-            if e not in out:
-                out.append(e)
-        return out
-    return (lambda uri: node.get(term_id(uri), [])), sub_parts
+            d = os.path.join(data_dir, "classSubPart_index_%d__%s" % (n, part))
+            tt = parquet_io.read_table(d)
+            sub_cache[part] = dict(zip(tt.column("uri").to_pylist(), tt.column("parts").to_pylist()))
+        return [x for x in sub_cache[part].get(uri, "").split(",") if x]
+    return (lambda uri: node.get(uri, [])), sub_parts
 
 
 def main(argv=None) -> int:

@@ -74,3 +74,42 @@ def assert_same_as_oracle(got, ref):
     for k in ("schema_cc", "schema_node_freq", "schema_node_count"):
         if k in got and k in ref:
             assert got[k] == ref[k], "%s differs" % k
+
+
+def assert_layout_equals_oracle(base, dataset, n, local_dir, ref):
+    """The Parquet files of an on-disk layout (whoever wrote them) and the text files beside them against the
+    oracle's artefacts: part files, vertical-partition directories, node index, VP index, partition_stat, statistics."""
+    import os
+
+    import pyarrow.parquet as pq
+    from opus_amd.host import parquet_io as P
+    root = P.cluster_dir(base, dataset, n)
+    assert sorted(P.vp_table_keys(base, dataset, n)) == sorted("%s-%s" % k for k in ref["vp"])
+    for (pname, sub), rows in ref["vp"].items():
+        t = P.read_table(os.path.join(root, pname, sub))
+        assert t.column_names == ["_1", "_2"]
+        assert sorted(zip(t["_1"].to_pylist(), t["_2"].to_pylist())) == sorted(rows), (pname, sub)
+        assert os.path.exists(os.path.join(root, pname, "_SUCCESS"))  # partitionBy leaves it at the root of the write
+    for q, part in enumerate(ref["parts"]):
+        files = [f for f in os.listdir(root) if f.startswith("part-%05d-" % q)]
+        assert len(files) == (1 if part else 0)
+        if part:
+            t = pq.read_table(os.path.join(root, files[0]))
+            assert t.column_names == ["_1", "_2", "_3"]
+            assert set(zip(t["_1"].to_pylist(), t["_2"].to_pylist(), t["_3"].to_pylist())) == part
+            assert t.num_rows == len(part)
+    # nothing but what Spark would leave there: part files, partition directories, _SUCCESS
+    assert all(f.startswith("part-") and f.endswith(".parquet") or f == "_SUCCESS" or os.path.isdir(os.path.join(root, f)) for f in os.listdir(root))
+    t = P.read_table(os.path.join(base, dataset + "_data", "node_index_%d" % n))
+    assert t.column_names == ["uri", "uriType"]
+    assert set(zip(t["uri"].to_pylist(), t["uriType"].to_pylist())) == ref["node_index"] and t.num_rows == len(ref["node_index"])
+    for pname, idx in ref["vp_index"].items():
+        t = P.read_table(os.path.join(base, dataset + "_data", "classSubPart_index_%d__%s" % (n, pname)))
+        assert t.column_names == ["uri", "parts"]
+        got = {u: frozenset(p.split(",")) for u, p in zip(t["uri"].to_pylist(), t["parts"].to_pylist())}
+        assert got == idx and t.num_rows == len(idx), pname
+    lines = open(os.path.join(local_dir, dataset + "_local", "partition_stat.txt_%d_bal" % n)).read().split("\n")
+    assert {ln.split(" ")[0]: int(ln.split(" ")[1]) for ln in lines if ln.startswith("00")} == ref["partition_stat"]
+    part_lines = {ln.split(" ")[0]: int(ln.split(" ")[1]) for ln in lines if ln.startswith("part-")}
+    assert part_lines == {f: len(ref["parts"][int(f[5:10])]) for f in os.listdir(root) if f.startswith("part-")}
+    assert set(open(os.path.join(local_dir, dataset + "_local", "statistics.txt_%d" % n)).read().split("\n")) - {""} == ref["statistics"]

@@ -46,6 +46,10 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DAP - partitioning time:" in p.stdout
 
+    # The one command has left the reference's layout: Parquet files with the Scala tools' schemas where they look for
+    # them (DAP.scala:364-367, 412, 433-437, 499), written by the library itself (no Python in between)
+    from parity_util import assert_layout_equals_oracle
+    assert_layout_equals_oracle(base + "/", "LUBM", 4, str(cwd), ref)
     clusters = os.path.join(base, "LUBM_data", "cluster", "clusters_4_bal")
     # VP directory names = the oracle's (partition, _3=<sanitised predicate>) keys
     got_dirs = {(d, s) for d in os.listdir(clusters) if os.path.isdir(os.path.join(clusters, d))
@@ -135,3 +139,41 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
         assert sorted(got) == sorted(tuple(r) for r in rows), name
         rec = dict(ln.split(": ", 1) for ln in (cwd / "results" / "LUBM" / "cold_4_bal" / ("results_%d.txt" % tp)).read_text().splitlines()[-5:])
         assert rec["Query"] == name and int(rec["Result_count"]) == len(rows) and rec["partitions"] == ",".join(partitions)
+
+
+def test_layout_written_by_dx_dap_serves_a_fresh_engine_through_its_parquet_files(lubm1, tmp_path):
+    """Only dx-dap runs; the translator's command line and parquet_io.import_layout then work from the files alone, as
+    the Scala tools would (spark.read.load of the same directories), and the queries answer as the oracle says."""
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_BINDINGS, Engine
+    from opus_amd.host import parquet_io as P
+    from oracle import query_oracle
+    ref = lubm1["oracle"]
+    cwd = tmp_path
+    (cwd / "instances.nt").write_bytes(bytes(lubm1["bytes"]))
+    (cwd / "LUBM_local").mkdir()
+    (cwd / "LUBM_local" / "class_index.txt_4_bal").write_text(lubm1["class_index"])
+    base = str(cwd / "store")
+    p = subprocess.run([os.path.join(BIN, "dx-dap"), "LUBM", "4", base, str(cwd / "instances.nt"), "unused"], cwd=cwd,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    (cwd / "queries").mkdir()
+    for name, text in lubm.queries(0).items():
+        (cwd / "queries" / name).write_text(text)
+    tenv = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-m", "opus_amd.host.translator", "LUBM", "4", base, str(cwd / "queries")], cwd=cwd,
+                       capture_output=True, text=True, env=tenv, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    e = Engine(0)
+    try:
+        for name in ("Q1.txt", "Q4.txt", "Q7.txt", "Q9.txt", "Q14.txt"):
+            tr = (cwd / "queries" / "translated_queries_4_bal" / name).read_text()
+            want = query_oracle.run_query(ref["vp"], tr)
+            qm, parts, _ = query_oracle.parse_translated_file(tr)
+            rows = P.import_layout(e, base + "/", "LUBM", 4, keys=dict.fromkeys(parts))
+            assert sum(rows[k] for k in parts) == want["load_data"]
+            res = e.query(next(iter(qm.values())), DX_QUERY_BINDINGS)
+            got, cols = res.rows()
+            assert res.count == want["count"] and cols == want["columns"] and got == want["rows"], name
+    finally:
+        e.close()

@@ -21,29 +21,9 @@ def test_export_import_round_trip(tmp_path, lubm1):
         stat = P.export_layout(e, base, "lubm", local_dir=str(tmp_path))
     finally:
         e.close()
-    root = P.cluster_dir(base, "lubm", 4)
-    # files against the oracle
-    assert sorted(P.vp_table_keys(base, "lubm", 4)) == sorted("%s-%s" % k for k in ref["vp"])
-    for (pname, sub), rows in ref["vp"].items():
-        t = P.read_table(os.path.join(root, pname, sub))
-        assert sorted(zip(t["_1"].to_pylist(), t["_2"].to_pylist())) == sorted(rows), (pname, sub)
-    for q, part in enumerate(ref["parts"]):
-        files = [f for f in os.listdir(root) if f.startswith("part-%05d-" % q)]
-        assert len(files) == (1 if part else 0)
-        if part:
-            import pyarrow.parquet as pq
-            t = pq.read_table(os.path.join(root, files[0]))
-            assert set(zip(t["_1"].to_pylist(), t["_2"].to_pylist(), t["_3"].to_pylist())) == part
-    t = P.read_table(os.path.join(base, "lubm_data", "node_index_4"))
-    assert set(zip(t["uri"].to_pylist(), t["uriType"].to_pylist())) == ref["node_index"]
-    for pname, idx in ref["vp_index"].items():
-        t = P.read_table(os.path.join(base, "lubm_data", "classSubPart_index_4__" + pname))
-        got = {u: frozenset(p.split(",")) for u, p in zip(t["uri"].to_pylist(), t["parts"].to_pylist())}
-        assert got == idx, pname
-    lines = open(os.path.join(str(tmp_path), "lubm_local", "partition_stat.txt_4_bal")).read().split("\n")
-    assert {l.split(" ")[0]: int(l.split(" ")[1]) for l in lines if l.startswith("00")} == ref["partition_stat"]
+    from parity_util import assert_layout_equals_oracle
+    assert_layout_equals_oracle(base, "lubm", 4, str(tmp_path), ref)
     assert {k: v for k, v in stat.items() if k.startswith("00")} == ref["partition_stat"]
-    assert set(open(os.path.join(str(tmp_path), "lubm_local", "statistics.txt_4")).read().split("\n")) - {""} == ref["statistics"]
 
     # a fresh engine that has only the Parquet files
     ni = {}
