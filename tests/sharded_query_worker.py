@@ -56,12 +56,16 @@ def main(out_path):
     results = {}
     # every statement twice: with the default rule (at this size every join sends its small side to all ranks) and with
     # every join redistributing both sides by the join key
-    runs = [(name, st, None) for name, st in statements.items()] + [(name + "#hashed", st, "0") for name, st in statements.items()]
-    for name, (sql, parts), small_side in runs:
-        if small_side is None:
-            os.environ.pop("DX_SMALL_SIDE_ROWS", None)
-        else:
-            os.environ["DX_SMALL_SIDE_ROWS"] = small_side
+    # and a third time as the library runs them by default: a statement whose tables all lie in one rank's partitions is
+    # answered by that rank alone (the first two runs switch that off, so that every statement takes the exchanges)
+    runs = [(name, st, None, "1") for name, st in statements.items()] + [(name + "#hashed", st, "0", "1") for name, st in statements.items()] + \
+           [(name + "#owner", st, None, None) for name, st in statements.items()]
+    for name, (sql, parts), small_side, no_owner in runs:
+        for var, val in (("DX_SMALL_SIDE_ROWS", small_side), ("DX_NO_SINGLE_OWNER", no_owner)):
+            if val is None:
+                os.environ.pop(var, None)
+            else:
+                os.environ[var] = val
         # together
         e.set_comm(comm)
         e.unload_all()
@@ -89,6 +93,7 @@ def main(out_path):
     from opus_amd.engine import DxError
     failures = {}
     os.environ.pop("DX_SMALL_SIDE_ROWS", None)
+    os.environ["DX_NO_SINGLE_OWNER"] = "1"   # the failing statement takes the exchanges; the single-owner case follows below
     e.set_comm(comm)
     e.comm_selftest()
     sql, parts = statements["Q2.txt"]
@@ -115,6 +120,23 @@ def main(out_path):
     e.load_tables_sharded(parts)
     failures["after"] = e.query(sql, DX_QUERY_COUNT).count
     failures["want_after"] = results["Q2.txt"]["count"]
+    # the single-owner case: the owner has lost the statement's tables, the other rank has nothing to do with them
+    os.environ.pop("DX_NO_SINGLE_OWNER", None)
+    own_name = next(n for n, r in results.items() if n.endswith("#owner") and "alone" in r["plan"] and "Q" in n)
+    sql1, parts1 = statements[own_name.split("#")[0]]
+    e.unload_all()
+    e.load_tables_sharded(parts1)
+    if owner(int(parts1[0].split("-")[0])) == rank:
+        e.unload_all()
+    try:
+        e.query(sql1, DX_QUERY_COUNT)
+        failures["owner_lost_table"] = 0
+    except DxError as ex:
+        failures["owner_lost_table"] = ex.code
+    e.unload_all()
+    e.load_tables_sharded(parts1)
+    failures["owner_after"] = e.query(sql1, DX_QUERY_COUNT).count
+    failures["owner_want_after"] = results[own_name]["count"]
     all_f = [None] * world
     dist.all_gather_object(all_f, failures)
     if rank == 0:

@@ -35,7 +35,15 @@ def test_two_ranks_answer_like_one(tmp_path):
     for f in failures:   # one rank's planner did not find a table / a table's files are missing: both ranks return that error
         assert f["missing_table"] == -2 and f["missing_file"] == -2, failures
         assert f["after"] == f["want_after"]
-    assert len(res) >= 28
+        assert f["owner_lost_table"] == -2 and f["owner_after"] == f["owner_want_after"], failures
+    assert len(res) >= 42
+    # statements whose tables all lie in one rank's partitions: answered there, one sum, no rows moved
+    alone_runs = [n for n, r in res.items() if n.endswith("#owner") and "alone: all tables in its partitions" in r["plan"]]
+    assert len(alone_runs) >= 5
+    for n in alone_runs:
+        assert sorted(res[n]["share_sizes"])[:-1] == [0] * (len(res[n]["share_sizes"]) - 1), n
+        assert "0 host exchanges, 0 data, 1 sum" in res[n]["plan"]
+    assert any(n.endswith("#owner") and "alone" not in r["plan"] for n, r in res.items())  # and some that span both ranks
     spread = 0
     for name, r in res.items():
         a = r["alone"]
