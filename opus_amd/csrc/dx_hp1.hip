@@ -2065,12 +2065,22 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     }
   }
   if (n_rec) hipLaunchKernelGGL(k_vertex_masks, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, O.p, kind.p, n_rec, Pm.p, M.p);
-  if (sharded && n_terms) {  // a vertex's types may be declared in another rank's part of the text
-    DevBuf<uint64_t> gathered(pool, (size_t)cm.world * n_terms);
-    const std::vector<uint64_t> counts(cm.world, n_terms);
+  if (sharded && n_terms) {
+    // A vertex's types may be declared in another rank's part of the text: the ranks' masks are OR-ed. Rank r does it
+    // for the r-th slice of the id range: every rank sends it that slice of its own masks (one all-to-all), it folds
+    // the W slices, and the folded slices are gathered: 2 x 8 bytes per term over the links instead of W x 8.
+    const int W = cm.world;
+    const uint64_t per = ((uint64_t)n_terms + W - 1) / W;
+    auto slice_len = [&](int r) { const uint64_t b = std::min<uint64_t>(n_terms, per * r), e = std::min<uint64_t>(n_terms, per * (r + 1)); return e - b; };
+    const uint64_t mine = slice_len(cm.rank);
+    std::vector<uint64_t> send(W), recv(W, mine), lens(W);
+    for (int r = 0; r < W; ++r) send[r] = lens[r] = slice_len(r);
+    DevBuf<uint64_t> slices(pool, std::max<uint64_t>(1, (uint64_t)W * mine)), folded(pool, std::max<uint64_t>(1, mine));
     DX_HIP(hipStreamSynchronize(s));
-    comm_ok(cm.allgather(cm.user, M.p, n_terms, gathered.p, counts.data(), 8), "allgather of the vertex masks");
-    hipLaunchKernelGGL(k_or_gathered, dim3(blocks(n_terms)), dim3(256), 0, s, gathered.p, cm.world, (uint64_t)n_terms, M.p);
+    comm_ok(cm.exchange(cm.user, M.p, send.data(), slices.p, recv.data(), 8), "exchange of the vertex masks' slices");
+    if (mine) hipLaunchKernelGGL(k_or_gathered, dim3(blocks(mine)), dim3(256), 0, s, slices.p, W, mine, folded.p);
+    DX_HIP(hipStreamSynchronize(s));
+    comm_ok(cm.allgather(cm.user, folded.p, mine, M.p, lens.data(), 8), "allgather of the folded vertex masks");
     DX_HIP(hipStreamSynchronize(s));
   }
   tm.mark();
