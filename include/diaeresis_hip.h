@@ -147,13 +147,20 @@ int dx_measures_classes(dx_ctx* ctx, int64_t* class_term, int64_t* node_freq, in
 int dx_measures_cc(dx_ctx* ctx, int64_t* sub_type, int64_t* pred, int64_t* obj_type, int64_t* rows, int64_t* dist);
 int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
 
-/* Writes <base><dataset>_data/... and <dataset>_local/... as the reference lays them out
- * (Constatnts.scala:9-40), with int64 column files beside the directory names the Scala tools expect. */
+/* Writes what DAP.main leaves behind (DAP.scala:85-94; paths of Constatnts.scala:9-40), as Parquet files with the
+ * Scala tools' schemas (utils/Types.scala:7-16): the first-level partitions (_1,_2,_3; DAP.scala:364-367), the vertical
+ * partition directories 0000i/_3=<predicate> (_1,_2; :433-437), node_index_<N> (uri, uriType; :405-412),
+ * classSubPart_index_<N>__0000i (uri, parts; :496-499), _SUCCESS files, and <dataset>_local/statistics.txt_<N>,
+ * partition_stat.txt_<N>_bal, statTables.txt. Beside them, under <base><dataset>_data/dx_<N>/ (a directory the Scala
+ * tools never list), the dictionary and the tables' id columns for dx_open_dataset / dx_load_table.
+ * DX_E_INVAL if the clusters directory exists (the reference skips the stage then, DAP.scala:86). */
 int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
 
 /* ---- query processor ------------------------------------------------------------------------------ */
 /* Points the context at a layout written by dx_part_write_layout (replaces the path arithmetic of
- * QueryProcessor.loadDataset, QueryProcessor.scala:308-325) and loads its dictionary. */
+ * QueryProcessor.loadDataset, QueryProcessor.scala:308-325) and loads its dictionary from <dataset>_data/dx_<N>/.
+ * DX_E_NOENT when that directory is missing (a layout written by the Scala tools: bring its tables in with
+ * dx_dictionary_load + dx_load_table_ids). */
 int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions);
 /* Replaces QueryProcessor.loadDataset + preloadTables (QueryProcessor.scala:210-236, 308-339) for one
  * entry of the `partitions` line ("00001-_3=<sanitised predicate>"): makes the table resident in HBM and
@@ -208,10 +215,13 @@ void dx_result_free(dx_result* r);
 /* ---- query processor on several GPUs ------------------------------------------------------------------
  * One process and one dx_ctx per GPU. Every rank opens the same layout (one dictionary, so term ids agree),
  * loads the tables of the first-level partitions it owns with dx_load_table and names the others with
- * dx_declare_remote_table. dx_query is then collective: every rank passes the same statement; scans and
- * filters run where the table lives, and before each join both inputs are redistributed by a hash of the
- * join key. This is the exchange Spark plans inside spark.sqlContext.sql (QueryProcessor.scala:187,192,
- * spark.sql.shuffle.partitions :124,139), with the GPUs of the node in the place of its shuffle partitions.
+ * dx_declare_remote_table (dx_load_tables_sharded does both). dx_query is then collective: every rank passes the
+ * same statement. A statement whose tables all lie in first-level partitions of one rank (partition q belongs to
+ * rank q % world; the partition is read off the table names) is answered by that rank alone, and one sum brings the
+ * count to the others. Otherwise scans and filters run where the table lives, and before each join the small side is
+ * sent to all ranks or both inputs are redistributed by a hash of the join key. This is the exchange Spark plans
+ * inside spark.sqlContext.sql (QueryProcessor.scala:187,192, spark.sql.shuffle.partitions :124,139) and its broadcast
+ * of a small side, with the GPUs of the node in the place of its shuffle partitions.
  * The library asks five collectives of a communicator (struct dx_comm). dx_comm_rccl_init makes one over RCCL
  * inside the library (production: xGMI between the GPUs of a node); a host may hand in its own instead with
  * dx_set_comm (the tests run two ranks over gloo that way). Buffers named *_dev are device memory of this rank's
