@@ -443,18 +443,22 @@ static void instance_graph(dx_ctx* ctx, std::vector<int64_t>& vterms, std::vecto
   if (!es) return;
   std::vector<int64_t> rank(d.n_terms, -1);
   for (size_t i = 0; i < vterms.size(); ++i) rank[vterms[i]] = (int64_t)i;
-  std::vector<uint64_t> keys(ps.n_uniq_slots);
-  fetch(keys.data(), ps.uniq.p, keys.size() * 8);
-  const uint64_t tm = (1ull << ps.bits_term) - 1;
-  for (size_t i = 0; i < keys.size(); ++i) {
-    if (i && keys[i] == keys[i - 1]) continue;
-    const uint32_t pidx = (uint32_t)(keys[i] >> (2 * ps.bits_term));
-    const uint64_t s = (keys[i] >> ps.bits_term) & tm, o = keys[i] & tm;
-    if (pidx == ps.type_pidx || (flags[o] & 1)) continue;
-    es->push_back(rank[s]);
-    ed->push_back(rank[o]);
-    ep->push_back(ps.pred_terms[pidx]);
-  }
+  auto edges = [&](auto zero, const void* dev_keys) {
+    using K = decltype(zero);
+    std::vector<K> keys(ps.n_uniq_slots);
+    fetch(keys.data(), dev_keys, keys.size() * sizeof(K));
+    const K tm = ((K)1 << ps.bits_term) - 1;
+    for (size_t i = 0; i < keys.size(); ++i) {
+      if (i && keys[i] == keys[i - 1]) continue;
+      const uint32_t pidx = (uint32_t)(keys[i] >> (2 * ps.bits_term));
+      const uint64_t s = (uint64_t)((keys[i] >> ps.bits_term) & tm), o = (uint64_t)(keys[i] & tm);
+      if (pidx == ps.type_pidx || (flags[o] & 1)) continue;
+      es->push_back(rank[s]);
+      ed->push_back(rank[o]);
+      ep->push_back(ps.pred_terms[pidx]);
+    }
+  };
+  if (ps.wide_keys) edges((u128)0, ps.uniq_w.p); else edges((uint64_t)0, ps.uniq.p);
 }
 
 int dx_instance_graph_sizes(dx_ctx* ctx, int64_t* n_vertices, int64_t* n_edges) {

@@ -991,24 +991,29 @@ k_list_preds(const uint8_t* __restrict__ is_pred, const uint32_t* __restrict__ p
 }
 
 // ---- 5. sort keys, placement masks -----------------------------------------------------------------------
+// K: the key word, uint64_t when predicate index and two term ids fit 64 bits (every LUBM size), u128 beyond
+// (tens of thousands of predicates over hundreds of millions of terms).
+template <typename K>
 __global__ void __launch_bounds__(256)
 k_pack_keys(const uint32_t* __restrict__ S, const uint32_t* __restrict__ P, const uint32_t* __restrict__ O, uint32_t n_rec,
-            const uint32_t* __restrict__ pred_index, int bits_term, uint64_t* __restrict__ keys) {
+            const uint32_t* __restrict__ pred_index, int bits_term, K* __restrict__ keys) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rec) return;
-  keys[r] = ((uint64_t)pred_index[P[r]] << (2 * bits_term)) | ((uint64_t)S[r] << bits_term) | (uint64_t)O[r];
+  keys[r] = ((K)pred_index[P[r]] << (2 * bits_term)) | ((K)S[r] << bits_term) | (K)O[r];
 }
 
 struct Unpacked { uint32_t pidx, s, o; };
-__device__ __forceinline__ Unpacked unpack(uint64_t k, int bits_term) {
-  const uint64_t tm = (1ull << bits_term) - 1;
+template <typename K>
+__device__ __forceinline__ Unpacked unpack(K k, int bits_term) {
+  const K tm = ((K)1 << bits_term) - 1;
   return {(uint32_t)(k >> (2 * bits_term)), (uint32_t)((k >> bits_term) & tm), (uint32_t)(k & tm)};
 }
 
 // mask[i] = partitions of sorted triple i (0 for a duplicate of its predecessor); also counts
 // distinct triples, distinct edges and node-index rows.
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+k_place(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
         const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, uint64_t owned /*partitions this rank keeps*/,
         uint64_t* __restrict__ mask, uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges, 2 rows over all partitions*/) {
   // Grid-stride: the counters are hit once per block at the end, and the grid is about a thousand blocks.
@@ -1016,7 +1021,7 @@ k_place(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t t
   uint32_t uq = 0, ed = 0;
   uint64_t rows = 0;  // a triple is one row in each of its partitions: the split's 32-bit positions must hold the sum
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t k = keys[i];
+    const K k = keys[i];
     uint64_t m = 0;
     uint8_t nf = 0;
     if (i == 0 || keys[i - 1] != k) {
@@ -1081,8 +1086,9 @@ k_split_count(const uint64_t* __restrict__ mask, uint32_t n, int nparts, uint32_
   if (threadIdx.x < nparts) counts[(size_t)threadIdx.x * ntiles + blockIdx.x] = c[threadIdx.x];
 }
 
+template <typename K>
 __global__ void __launch_bounds__(SP_THREADS)
-k_split_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ mask, uint32_t n, int nparts, int bits_term,
+k_split_scatter(const K* __restrict__ keys, const uint64_t* __restrict__ mask, uint32_t n, int nparts, int bits_term,
                 const uint32_t* __restrict__ offs, unsigned ntiles, int64_t* __restrict__ row_s, int64_t* __restrict__ row_o,
                 uint32_t* __restrict__ row_p) {
   __shared__ uint32_t wcnt[4][DX_MAX_PARTITIONS];
@@ -1175,8 +1181,9 @@ k_table_starts(const uint32_t* __restrict__ row_p, const uint32_t* __restrict__ 
 }
 
 // ---- 7. node index, VP index ------------------------------------------------------------------------------
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_node_index(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ node_flag, const uint32_t* __restrict__ pos, uint32_t n,
+k_node_index(const K* __restrict__ keys, const uint8_t* __restrict__ node_flag, const uint32_t* __restrict__ pos, uint32_t n,
              int bits_term, int64_t* __restrict__ ns, int64_t* __restrict__ no, uint8_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !node_flag[i]) return;
@@ -1421,8 +1428,9 @@ __device__ __forceinline__ uint64_t owners_of(uint64_t m, int world) {
   for (; m; m &= m - 1) d |= 1ull << ((__ffsll((long long)m) - 1) % world);
   return d;
 }
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_route_count(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+k_route_count(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
               const uint64_t* __restrict__ Pm, const uint64_t* __restrict__ M, int world, uint64_t* __restrict__ owners,
               unsigned long long* __restrict__ counts) {
   __shared__ uint32_t c[DX_MAX_PARTITIONS];
@@ -1436,9 +1444,10 @@ k_route_count(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint
   __syncthreads();
   if (threadIdx.x < world && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c[threadIdx.x]);
 }
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_route_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ owners, uint32_t n, int world,
-                unsigned long long* __restrict__ cursor, uint64_t* __restrict__ out) {
+k_route_scatter(const K* __restrict__ keys, const uint64_t* __restrict__ owners, uint32_t n, int world,
+                unsigned long long* __restrict__ cursor, K* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -1446,7 +1455,7 @@ k_route_scatter(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ 
   for (uint32_t rd = 0; rd < rounds; ++rd) {
     const uint32_t i = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t d = i < n ? owners[i] : 0;
-    const uint64_t k = i < n ? keys[i] : 0;
+    const K k = i < n ? keys[i] : (K)0;
     for (int p = 0; p < world; ++p) {  // wave-uniform
       const bool go = (d >> p) & 1;
       const uint64_t b = __ballot(go);
@@ -1861,6 +1870,13 @@ void run_partition(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std
   agree_or_throw(ctx, err);
 }
 
+// runs a statement with K = the key word of this partition run and keys = its sorted key array
+#define DX_WITH_KEYS(...)                                                                 \
+  do {                                                                                    \
+    if (ps.wide_keys) { using K = u128; const K* keys = ps.uniq_w.p; __VA_ARGS__; }       \
+    else { using K = uint64_t; const K* keys = ps.uniq.p; __VA_ARGS__; }                  \
+  } while (0)
+
 static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,
                                int nparts) {
   hipStream_t s = ctx->stream;
@@ -2131,57 +2147,66 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   }
   d_preds.reset();
   const int bits_term = bits_for(n_terms ? n_terms : 1), bits_pred = bits_for(np ? np : 1);
-  if (bits_pred + 2 * bits_term > 64 || bits_for(nparts) + bits_term + 1 + bits_pred > 64)
-    throw DxError(DX_E_RANGE, "dictionary too large for 64-bit packed sort keys on one GPU");
+  if (bits_for(nparts) + bits_term + 1 + bits_pred > 64)
+    throw DxError(DX_E_RANGE, "dictionary too large for 64-bit packed VP index entries on one GPU");
+  // (predicate index, subject, object) in one word: 64 bits hold every LUBM size (5 + 2 x 28 bits at LUBM-1300); a
+  // schema of tens of thousands of predicates over hundreds of millions of terms takes 128-bit words, sorted by the
+  // same passes with twice the bytes. DX_FORCE_WIDE_KEYS=1 takes that path on any input (how the tests reach it).
+  ps.wide_keys = bits_pred + 2 * bits_term > 64 || (getenv("DX_FORCE_WIDE_KEYS") && *getenv("DX_FORCE_WIDE_KEYS") == '1');
   ps.bits_term = bits_term;
   for (uint32_t i = 0; i < np; ++i)
     if (ps.pred_terms[i] == type_term) ps.type_pidx = i;
-  ps.uniq = DevBuf<uint64_t>(pool, n_rec);
   ps.n_uniq_slots = n_rec;
-  if (n_rec) hipLaunchKernelGGL(k_pack_keys, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, P.p, O.p, n_rec, pred_index.p, bits_term, ps.uniq.p);
-  S.reset(); P.reset(); O.reset(); kind.reset(); fact.reset();
-  if (sharded) {
-    // every triple goes to the ranks that own one of its partitions (CustomPartitioner, DAP.scala:541-551);
-    // what arrives is sorted, de-duplicated across ranks and placed like the triples of a single GPU
-    DevBuf<uint64_t> owners(pool, n_rec);
-    DevBuf<unsigned long long> counts(pool, 2 * DX_MAX_PARTITIONS);
-    DX_HIP(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * 2 * DX_MAX_PARTITIONS, s));
-    if (n_rec)
-      hipLaunchKernelGGL(k_route_count, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx,
-                         ps.term_flags.p, Pm.p, M.p, cm.world, owners.p, counts.p);
-    std::vector<unsigned long long> h(cm.world);
-    fetch.add(h.data(), counts.p, sizeof(unsigned long long) * cm.world);
-    fetch.sync();
-    std::vector<uint64_t> send(cm.world), recv(cm.world);
-    std::vector<unsigned long long> cur(cm.world);
-    unsigned long long run = 0;
-    for (int p = 0; p < cm.world; ++p) { send[p] = h[p]; cur[p] = run; run += h[p]; }
-    if (run >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 routed triples on one GPU");  // reaches the checkpoint below from the handler
-    DX_HIP(hipMemcpyAsync(counts.p + DX_MAX_PARTITIONS, cur.data(), sizeof(unsigned long long) * cm.world, hipMemcpyHostToDevice, s));
-    DevBuf<uint64_t> outbox(pool, run);
-    if (n_rec)
-      hipLaunchKernelGGL(k_route_scatter, dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, ps.uniq.p, owners.p, n_rec, cm.world,
-                         counts.p + DX_MAX_PARTITIONS, outbox.p);
-    DX_HIP(hipStreamSynchronize(s));
-    DX_HIP(hipGetLastError());
-    checkpoint();
-    comm_ok(cm.exchange_host(cm.user, send.data(), recv.data(), 1), "exchange_host");
-    uint64_t n_in = 0;
-    for (int p = 0; p < cm.world; ++p) n_in += recv[p];
-    {  // an inbox of 2^32 triples is this rank's problem alone: all ranks hear of it before the triples move
-      LocalError e;
-      if (n_in >= (1ull << 32)) { e.code = DX_E_RANGE; e.msg = "more than 2^32 triples arrive on one GPU"; }
-      agree_or_throw(ctx, e);
+  auto pack_route_sort = [&](auto& uniq, auto& local_keys) {
+    using KBuf = std::remove_reference_t<decltype(uniq)>;
+    using K = std::remove_pointer_t<decltype(uniq.p)>;
+    uniq = KBuf(pool, n_rec);
+    if (n_rec) hipLaunchKernelGGL((k_pack_keys<K>), dim3(blocks(n_rec)), dim3(256), 0, s, S.p, P.p, O.p, n_rec, pred_index.p, bits_term, uniq.p);
+    S.reset(); P.reset(); O.reset(); kind.reset(); fact.reset();
+    if (sharded) {
+      // every triple goes to the ranks that own one of its partitions (CustomPartitioner, DAP.scala:541-551);
+      // what arrives is sorted, de-duplicated across ranks and placed like the triples of a single GPU
+      DevBuf<uint64_t> owners(pool, n_rec);
+      DevBuf<unsigned long long> counts(pool, 2 * DX_MAX_PARTITIONS);
+      DX_HIP(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * 2 * DX_MAX_PARTITIONS, s));
+      if (n_rec)
+        hipLaunchKernelGGL((k_route_count<K>), dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, uniq.p, n_rec, bits_term, ps.type_pidx,
+                           ps.term_flags.p, Pm.p, M.p, cm.world, owners.p, counts.p);
+      std::vector<unsigned long long> h(cm.world);
+      fetch.add(h.data(), counts.p, sizeof(unsigned long long) * cm.world);
+      fetch.sync();
+      std::vector<uint64_t> send(cm.world), recv(cm.world);
+      std::vector<unsigned long long> cur(cm.world);
+      unsigned long long run = 0;
+      for (int p = 0; p < cm.world; ++p) { send[p] = h[p]; cur[p] = run; run += h[p]; }
+      if (run >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 routed triples on one GPU");  // reaches the checkpoint below from the handler
+      DX_HIP(hipMemcpyAsync(counts.p + DX_MAX_PARTITIONS, cur.data(), sizeof(unsigned long long) * cm.world, hipMemcpyHostToDevice, s));
+      KBuf outbox(pool, run);
+      if (n_rec)
+        hipLaunchKernelGGL((k_route_scatter<K>), dim3(std::min(blocks(n_rec), 4096u)), dim3(256), 0, s, uniq.p, owners.p, n_rec, cm.world,
+                           counts.p + DX_MAX_PARTITIONS, outbox.p);
+      DX_HIP(hipStreamSynchronize(s));
+      DX_HIP(hipGetLastError());
+      checkpoint();
+      comm_ok(cm.exchange_host(cm.user, send.data(), recv.data(), 1), "exchange_host");
+      uint64_t n_in = 0;
+      for (int p = 0; p < cm.world; ++p) n_in += recv[p];
+      {  // an inbox of 2^32 triples is this rank's problem alone: all ranks hear of it before the triples move
+        LocalError e;
+        if (n_in >= (1ull << 32)) { e.code = DX_E_RANGE; e.msg = "more than 2^32 triples arrive on one GPU"; }
+        agree_or_throw(ctx, e);
+      }
+      KBuf inbox(pool, n_in);
+      comm_ok(cm.exchange(cm.user, outbox.p, send.data(), inbox.p, recv.data(), (int)sizeof(K)), "exchange of the triples");
+      local_keys = std::move(uniq);
+      ps.n_local_keys = n_rec;
+      uniq = std::move(inbox);
+      n_rec = (uint32_t)n_in;
+      ps.n_uniq_slots = n_rec;
     }
-    DevBuf<uint64_t> inbox(pool, n_in);
-    comm_ok(cm.exchange(cm.user, outbox.p, send.data(), inbox.p, recv.data(), 8), "exchange of the triples");
-    ps.local_keys = std::move(ps.uniq);
-    ps.n_local_keys = n_rec;
-    ps.uniq = std::move(inbox);
-    n_rec = (uint32_t)n_in;
-    ps.n_uniq_slots = n_rec;
-  }
-  radix_sort_u64(pool, ps.uniq, n_rec, bits_pred + 2 * bits_term, s);
+    radix_sort_keys(pool, uniq, n_rec, bits_pred + 2 * bits_term, s);
+  };
+  if (ps.wide_keys) pack_route_sort(ps.uniq_w, ps.local_keys_w); else pack_route_sort(ps.uniq, ps.local_keys);
   tm.mark();
 
   // ---- 7. placement masks
@@ -2190,8 +2215,8 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DevBuf<unsigned long long> counters(pool, 3);
   DX_HIP(hipMemsetAsync(counters.p, 0, 24, s));
   if (n_rec)
-    hipLaunchKernelGGL(k_place, dim3(std::min(blocks(n_rec), 1024u)), dim3(256), 0, s, ps.uniq.p, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
-                       owned, mask.p, node_flag.p, counters.p);
+    DX_WITH_KEYS(hipLaunchKernelGGL((k_place<K>), dim3(std::min(blocks(n_rec), 1024u)), dim3(256), 0, s, keys, n_rec, bits_term, ps.type_pidx, ps.term_flags.p, Pm.p, M.p,
+                       owned, mask.p, node_flag.p, counters.p));
   tm.mark();
 
   // ---- 8. stable split by partition
@@ -2235,8 +2260,8 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   ps.row_o = DevBuf<int64_t>(pool, n_rows);
   ps.row_p = DevBuf<uint32_t>(pool, n_rows);
   if (n_rec)
-    hipLaunchKernelGGL(k_split_scatter, dim3(sp_tiles), dim3(SP_THREADS), 0, s, ps.uniq.p, mask.p, n_rec, nparts, bits_term, sp_counts.p,
-                       sp_tiles, ps.row_s.p, ps.row_o.p, ps.row_p.p);
+    DX_WITH_KEYS(hipLaunchKernelGGL((k_split_scatter<K>), dim3(sp_tiles), dim3(SP_THREADS), 0, s, keys, mask.p, n_rec, nparts, bits_term, sp_counts.p,
+                       sp_tiles, ps.row_s.p, ps.row_o.p, ps.row_p.p));
   if (np && pred_off[np]) {
     DevBuf<uint8_t> packed(pool, pred_off[np] + 16);
     hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * np)), dim3(256), 0, s, d.pool.p, d_pred_src.p, d_pred_off.p, (uint64_t)np, packed.p);
@@ -2259,8 +2284,8 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   st.n_node_index = n_node;
   ps.node_s = DevBuf<int64_t>(pool, n_node);
   ps.node_o = DevBuf<int64_t>(pool, n_node);
-  if (n_rec) hipLaunchKernelGGL(k_node_index, dim3(blocks(n_rec)), dim3(256), 0, s, ps.uniq.p, node_flag.p, node_pos.p, n_rec, bits_term,
-                                ps.node_s.p, ps.node_o.p, ps.term_flags.p);
+  if (n_rec) DX_WITH_KEYS(hipLaunchKernelGGL((k_node_index<K>), dim3(blocks(n_rec)), dim3(256), 0, s, keys, node_flag.p, node_pos.p, n_rec, bits_term,
+                                ps.node_s.p, ps.node_o.p, ps.term_flags.p));
   if (sharded && n_terms) {  // "this uri has a node-index row" has to hold on every rank, whoever keeps the row
     DevBuf<uint8_t> node_bit(pool, n_terms);
     hipLaunchKernelGGL(k_node_bit_out, dim3(blocks(n_terms)), dim3(256), 0, s, ps.term_flags.p, (uint64_t)n_terms, node_bit.p);

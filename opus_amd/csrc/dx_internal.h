@@ -88,6 +88,11 @@ void radix_sort_u64(DevPool& pool, uint64_t* keys, uint32_t* vals, size_t n, int
 // Keys only, on a pool allocation: `keys` may come back as another allocation of the same size (no final copy).
 void radix_sort_u64(DevPool& pool, DevBuf<uint64_t>& keys, size_t n, int key_bits, hipStream_t s);
 void radix_sort_u32(DevPool& pool, DevBuf<uint32_t>& keys, size_t n, int key_bits, hipStream_t s);  // keys of at most 32 bits: half the traffic
+// 128-bit keys (a dictionary too large for (predicate, subject, object) in 64 bits): twice the traffic per pass
+using u128 = unsigned __int128;
+void radix_sort_u128(DevPool& pool, DevBuf<u128>& keys, size_t n, int key_bits, hipStream_t s);
+inline void radix_sort_keys(DevPool& pool, DevBuf<uint64_t>& keys, size_t n, int key_bits, hipStream_t s) { radix_sort_u64(pool, keys, n, key_bits, s); }
+inline void radix_sort_keys(DevPool& pool, DevBuf<u128>& keys, size_t n, int key_bits, hipStream_t s) { radix_sort_u128(pool, keys, n, key_bits, s); }
 void fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 

@@ -36,9 +36,10 @@ inline int bits_for(uint64_t n) {
 }
 
 // lower bounds of two keys in the sorted key array (thread 0 and thread 1)
-__global__ void k_ms_bounds(const uint64_t* __restrict__ keys, uint32_t n, uint64_t k0, uint64_t k1, uint32_t* __restrict__ out) {
+template <typename K>
+__global__ void k_ms_bounds(const K* __restrict__ keys, uint32_t n, K k0, K k1, uint32_t* __restrict__ out) {
   if (threadIdx.x > 1) return;
-  const uint64_t k = threadIdx.x ? k1 : k0;
+  const K k = threadIdx.x ? k1 : k0;
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
@@ -47,19 +48,21 @@ __global__ void k_ms_bounds(const uint64_t* __restrict__ keys, uint32_t n, uint6
   out[threadIdx.x] = lo;
 }
 
-__global__ void __launch_bounds__(256) k_ms_heads(const uint64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ head) {
+template <typename K>
+__global__ void __launch_bounds__(256) k_ms_heads(const K* __restrict__ keys, uint32_t n, uint8_t* __restrict__ head) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
 // one entry per distinct (subject, class) of the type block; at[j] = its first position in the block
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_ms_type_entries(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ head, const uint32_t* __restrict__ pos, uint32_t n,
+k_ms_type_entries(const K* __restrict__ keys, const uint8_t* __restrict__ head, const uint32_t* __restrict__ pos, uint32_t n,
                   int bits_term, uint32_t* __restrict__ ent_s, uint32_t* __restrict__ ent_c, uint32_t* __restrict__ ent_at,
                   uint8_t* __restrict__ class_used) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !head[i]) return;
-  const uint64_t tm = (1ull << bits_term) - 1;
+  const K tm = ((K)1 << bits_term) - 1;
   const uint32_t j = pos[i];
   const uint32_t c = (uint32_t)(keys[i] & tm);
   ent_s[j] = (uint32_t)((keys[i] >> bits_term) & tm);
@@ -122,22 +125,25 @@ k_ms_node_freq(const uint32_t* __restrict__ ent_s, const uint32_t* __restrict__ 
 }
 
 struct Triple { uint32_t pidx, s, o; };
-__device__ __forceinline__ Triple unpack(uint64_t k, int bits_term) {
-  const uint64_t tm = (1ull << bits_term) - 1;
+template <typename K>
+__device__ __forceinline__ Triple unpack(K k, int bits_term) {
+  const K tm = ((K)1 << bits_term) - 1;
   return {(uint32_t)(k >> (2 * bits_term)), (uint32_t)((k >> bits_term) & tm), (uint32_t)(k & tm)};
 }
 // true for the first copy of a triple that is an edge of the instance graph
-__device__ __forceinline__ bool is_edge(const uint64_t* __restrict__ keys, uint32_t i, int bits_term, uint32_t type_pidx,
+template <typename K>
+__device__ __forceinline__ bool is_edge(const K* __restrict__ keys, uint32_t i, int bits_term, uint32_t type_pidx,
                                         const uint8_t* __restrict__ flags, Triple& t) {
-  const uint64_t k = keys[i];
+  const K k = keys[i];
   if (i && keys[i - 1] == k) return false;
   t = unpack(k, bits_term);
   return t.pidx != type_pidx && !(flags[t.o] & kFlagLiteral);
 }
 
 // node count per class, and per edge the number of cc rows it expands to (pairs of entries with non-empty class names)
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_ms_edges(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+k_ms_edges(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
            const uint32_t* __restrict__ type_off, const uint32_t* __restrict__ ent_c, const uint32_t* __restrict__ ent_at,
            const uint32_t* __restrict__ class_idx, const uint8_t* __restrict__ class_ok, uint32_t c0, uint32_t n_classes,
            unsigned long long* __restrict__ count, uint32_t* __restrict__ cc_rows /*null after the first pass*/) {
@@ -167,8 +173,9 @@ k_ms_edges(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_
 }
 
 // the cc rows: key = (subType, pred, objType, inst2) packed, value = product of the two multiplicities
+template <typename K>
 __global__ void __launch_bounds__(256)
-k_ms_cc_rows(const uint64_t* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
+k_ms_cc_rows(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pidx, const uint8_t* __restrict__ flags,
              const uint32_t* __restrict__ type_off, const uint32_t* __restrict__ ent_c, const uint32_t* __restrict__ ent_at,
              const uint32_t* __restrict__ class_idx, const uint8_t* __restrict__ class_ok, const uint32_t* __restrict__ cc_rows,
              const uint64_t* __restrict__ row_pos, int bits_class, int bits_pred, uint64_t* __restrict__ out_key,
@@ -220,10 +227,12 @@ k_ms_cc_finish(const uint32_t* __restrict__ g_start, uint32_t n_groups, uint32_t
 
 }  // namespace
 
-void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
+// K: the key word of the partition run (uint64_t, or u128 for a dictionary too large for it)
+template <typename K>
+static void run_measures_t(dx_ctx* ctx, dx_measure_sizes* out, const DevBuf<K>& uniq, const DevBuf<K>& local_keys) {
   const PartitionState& ps = ctx->part;
   const Dictionary& d = ctx->dict;
-  if (!ps.valid || !ps.uniq.p) throw DxError(DX_E_INVAL, "the measures need the state of a partition run in this context");
+  if (!ps.valid || (!uniq.p && ps.n_uniq_slots)) throw DxError(DX_E_INVAL, "the measures need the state of a partition run in this context");
   hipStream_t s = ctx->stream;
   DevPool& pool = ctx->pool;
   MeasureState& ms = ctx->measures;
@@ -235,20 +244,20 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   // for the largest configuration, against 288 GB of HBM -- sorts them and computes the (schema-sized) result for
   // itself: the same numbers on every rank, no partial results to merge.
   const dx_comm& cm = ctx->comm;
-  DevBuf<uint64_t> gathered;
-  const uint64_t* keys = ps.uniq.p;
+  DevBuf<K> gathered;
+  const K* keys = uniq.p;
   uint64_t n_keys = ps.n_uniq_slots;
   if (cm.world > 1) {
     if (!cm.allgather || !cm.exchange_host) throw DxError(DX_E_INVAL, "the communicator lacks the collectives of the measures");
-    if (!ps.local_keys.p && ps.n_local_keys) throw DxError(DX_E_INVAL, "the partition run was not made with this communicator");
+    if (!local_keys.p && ps.n_local_keys) throw DxError(DX_E_INVAL, "the partition run was not made with this communicator");
     std::vector<uint64_t> mine(cm.world, ps.n_local_keys), counts(cm.world, 0);
     if (cm.exchange_host(cm.user, mine.data(), counts.data(), 1)) throw DxError(DX_E_IO, "collective failed: exchange_host");
     n_keys = 0;
     for (uint64_t c : counts) n_keys += c;
-    gathered = DevBuf<uint64_t>(pool, n_keys);
+    gathered = DevBuf<K>(pool, n_keys);
     DX_HIP(hipStreamSynchronize(s));
-    if (cm.allgather(cm.user, ps.local_keys.p, ps.n_local_keys, gathered.p, counts.data(), 8)) throw DxError(DX_E_IO, "collective failed: allgather of the triples");
-    radix_sort_u64(pool, gathered, n_keys, bits_for(ps.pred_terms.size() ? ps.pred_terms.size() : 1) + 2 * ps.bits_term, s);
+    if (cm.allgather(cm.user, local_keys.p, ps.n_local_keys, gathered.p, counts.data(), (int)sizeof(K))) throw DxError(DX_E_IO, "collective failed: allgather of the triples");
+    radix_sort_keys(pool, gathered, n_keys, bits_for(ps.pred_terms.size() ? ps.pred_terms.size() : 1) + 2 * ps.bits_term, s);
     keys = gathered.p;
   }
   if (n_keys >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32 triples for the measures on one GPU");
@@ -279,19 +288,19 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
 
   // ---- the rdf:type block and the type lists
   DevBuf<uint32_t> bounds(pool, 2);
-  const uint64_t k0 = (uint64_t)ps.type_pidx << (2 * bt);
+  const K k0 = (K)ps.type_pidx << (2 * bt);
   const bool last_pred = ps.type_pidx + 1 >= np;  // the block then runs to the end of the keys
-  const uint64_t k1 = last_pred ? ~0ull : (uint64_t)(ps.type_pidx + 1) << (2 * bt);
-  hipLaunchKernelGGL(k_ms_bounds, dim3(1), dim3(64), 0, s, keys, n, k0, k1, bounds.p);
+  const K k1 = last_pred ? ~(K)0 : (K)(ps.type_pidx + 1) << (2 * bt);
+  hipLaunchKernelGGL((k_ms_bounds<K>), dim3(1), dim3(64), 0, s, keys, n, k0, k1, bounds.p);
   uint32_t hb[2] = {0, 0};
   fetch.add(hb, bounds.p, 8);
   fetch.sync();
   const uint32_t tb = hb[0], nt = (last_pred ? n : hb[1]) - hb[0];
   if (!nt) { finish(); return; }
-  const uint64_t* tkeys = keys + tb;
+  const K* tkeys = keys + tb;
   DevBuf<uint8_t> head(pool, nt);
   DevBuf<uint32_t> pos(pool, nt), d_tot(pool, 2);
-  hipLaunchKernelGGL(k_ms_heads, dim3(blocks(nt)), dim3(256), 0, s, tkeys, nt, head.p);
+  hipLaunchKernelGGL((k_ms_heads<K>), dim3(blocks(nt)), dim3(256), 0, s, tkeys, nt, head.p);
   exclusive_scan_u8_u32(pool, head.p, pos.p, nt, d_tot.p, s);
   uint32_t n_ent = 0;
   fetch.add(&n_ent, d_tot.p, 4);
@@ -301,7 +310,7 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   DevBuf<uint8_t> class_used(pool, n_terms);
   DevBuf<uint32_t> class_idx(pool, n_terms);
   DX_HIP(hipMemsetAsync(class_used.p, 0, n_terms, s));
-  hipLaunchKernelGGL(k_ms_type_entries, dim3(blocks(nt)), dim3(256), 0, s, tkeys, head.p, pos.p, nt, bt, ent_s.p, ent_c.p, ent_at.p,
+  hipLaunchKernelGGL((k_ms_type_entries<K>), dim3(blocks(nt)), dim3(256), 0, s, tkeys, head.p, pos.p, nt, bt, ent_s.p, ent_c.p, ent_at.p,
                      class_used.p);
   DX_HIP(hipMemcpyAsync(ent_at.p + n_ent, &nt, 4, hipMemcpyHostToDevice, s));
   exclusive_scan_u8_u32(pool, class_used.p, class_idx.p, n_terms, d_tot.p + 1, s);
@@ -324,7 +333,7 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   for (uint32_t c0 = 0; c0 < n_classes; c0 += MS_BINS) {
     hipLaunchKernelGGL(k_ms_node_freq, dim3(std::min(blocks(n_ent), MS_GRID)), dim3(256), 0, s, ent_s.p, ent_c.p, ent_at.p, n_ent,
                        ps.term_flags.p, class_idx.p, c0, n_classes, freq.p);
-    hipLaunchKernelGGL(k_ms_edges, dim3(std::min(blocks(n), MS_GRID)), dim3(256), 0, s, keys, n, bt, ps.type_pidx, ps.term_flags.p,
+    hipLaunchKernelGGL((k_ms_edges<K>), dim3(std::min(blocks(n), MS_GRID)), dim3(256), 0, s, keys, n, bt, ps.type_pidx, ps.term_flags.p,
                        type_off.p, ent_c.p, ent_at.p, class_idx.p, class_ok.p, c0, n_classes, count.p, c0 == 0 ? cc_rows.p : (uint32_t*)nullptr);
   }
 
@@ -350,7 +359,7 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
     const uint32_t r = (uint32_t)R;
     DevBuf<uint64_t> key(pool, r);
     DevBuf<uint32_t> w(pool, r);
-    hipLaunchKernelGGL(k_ms_cc_rows, dim3(blocks(n)), dim3(256), 0, s, keys, n, bt, ps.type_pidx, ps.term_flags.p, type_off.p, ent_c.p,
+    hipLaunchKernelGGL((k_ms_cc_rows<K>), dim3(blocks(n)), dim3(256), 0, s, keys, n, bt, ps.type_pidx, ps.term_flags.p, type_off.p, ent_c.p,
                        ent_at.p, class_idx.p, class_ok.p, cc_rows.p, row_pos.p, bits_class, bits_pred, key.p, w.p);
     radix_sort_u64(pool, key.p, w.p, r, 2 * bits_class + bits_pred + bt, s);
     DevBuf<uint8_t> head_g(pool, r), head_i(pool, r);
@@ -383,6 +392,12 @@ void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
   }
   DX_HIP(hipGetLastError());
   finish();
+}
+
+void run_measures(dx_ctx* ctx, dx_measure_sizes* out) {
+  const PartitionState& ps = ctx->part;
+  if (ps.wide_keys) run_measures_t<u128>(ctx, out, ps.uniq_w, ps.local_keys_w);
+  else run_measures_t<uint64_t>(ctx, out, ps.uniq, ps.local_keys);
 }
 
 }  // namespace dx

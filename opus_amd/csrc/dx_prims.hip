@@ -414,5 +414,8 @@ void radix_sort_u64(DevPool& pool, DevBuf<uint64_t>& keys, size_t n, int key_bit
 void radix_sort_u32(DevPool& pool, DevBuf<uint32_t>& keys, size_t n, int key_bits, hipStream_t s) {
   radix_sort_impl<uint32_t>(pool, keys.p, &keys, nullptr, n, key_bits, s);
 }
+void radix_sort_u128(DevPool& pool, DevBuf<u128>& keys, size_t n, int key_bits, hipStream_t s) {
+  radix_sort_impl<u128>(pool, keys.p, &keys, nullptr, n, key_bits, s);
+}
 
 }  // namespace dx

@@ -65,11 +65,15 @@ struct PartitionState {
   std::vector<uint64_t> vpi_s_base, vpi_o_base;
   int vpi_bits_term = 0, vpi_bits_pred = 0;
   // sorted distinct input triples packed as (pidx, s, o) plus what is needed to unpack them
+  // (64-bit words when predicate index + two term ids fit them, 128-bit words otherwise: wide_keys)
   DevBuf<uint64_t> uniq;
+  DevBuf<u128> uniq_w;
+  bool wide_keys = false;
   uint64_t n_uniq_slots = 0;          // length of uniq (duplicates are still in, flagged by equality with the predecessor)
   // several GPUs: uniq holds what was routed to this rank; the rank's own triples (packed alike, ids of the common
   // dictionary, unsorted) stay here for what needs every triple once, wherever it was placed
   DevBuf<uint64_t> local_keys;
+  DevBuf<u128> local_keys_w;
   uint64_t n_local_keys = 0;
   int bits_term = 0;
   uint32_t type_pidx = kNil;

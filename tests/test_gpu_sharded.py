@@ -60,14 +60,16 @@ def test_two_ranks_answer_like_one(tmp_path):
     assert res["Q2.txt#hashed"]["plan"] != res["Q2.txt"]["plan"]
 
 
-def test_two_ranks_partition_like_one(tmp_path):
+@pytest.mark.parametrize("wide_keys", ["0", "1"])
+def test_two_ranks_partition_like_one(tmp_path, wide_keys):
     """Each rank tokenises its half of the text; the ranks agree on one dictionary, exchange vertex facts and
     route the triples to the owners of their partitions. Together they must hold exactly what one GPU
     produces from the whole text, and answer the queries alike."""
     out = tmp_path / "sharded_partition.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "sharded_partition_worker.py"), str(out)]
-    env = dict(os.environ, DX_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # wide_keys: the 128-bit key words of a very large dictionary, forced on this small one (16 bytes per routed triple)
+    env = dict(os.environ, DX_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DX_FORCE_WIDE_KEYS=wide_keys)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     res = json.load(open(out))
