@@ -224,6 +224,7 @@ void dx_free(dx_ctx* ctx) {
     if (ctx->file_stage_ev[b]) (void)hipEventDestroy(ctx->file_stage_ev[b]);
   }
   if (ctx->part_host) (void)hipHostFree(ctx->part_host);
+  if (ctx->fetch_seq) (void)hipHostFree(ctx->fetch_seq);
   for (hipEvent_t e : ctx->part_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -17,6 +17,7 @@
 //   * sorting the distinct triples by (predicate, s, o) once and splitting them stably by partition
 //     bit yields every vertical-partition table as a contiguous, sorted slice.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 
 #include "dx_device.h"
@@ -706,11 +707,10 @@ k_entry_claim(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
   const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
   const uint64_t base = 3ull * tile_first[tile];
-  const uint32_t range = 3 * (tile_first[tile + 1] - tile_first[tile]);
   const uint32_t L = tile_leaders[tile];
-  for (uint32_t i = threadIdx.x & 63; i < range; i += 64) {
+  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) {
     uint8_t f = 0;
-    if (i < L) {
+    {
       const ulonglong2 en = ent[base + i];
       const uint64_t mine = en.x, h = en.y;
       uint64_t slot = h & mask, holder = kNoHolder;
@@ -750,15 +750,17 @@ k_entry_claim(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
 }
 
 // first[x] = 1 when entry x is its slot's representative (the earliest occurrence of its term in the text).
-// Only the entries k_entry_claim left undecided are looked at.
+// Only the entries k_entry_claim left undecided are looked at. tile_firsts[tile] = the tile's number of them.
 __global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
 k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
               const uint8_t* __restrict__ text, const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot,
-              const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ collision) {
+              const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ tile_firsts,
+              uint32_t* __restrict__ collision) {
   const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
   const uint64_t base = 3ull * tile_first[tile];
   const uint32_t L = tile_leaders[tile];
+  uint32_t mine_cnt = 0;
   for (uint32_t i = threadIdx.x & 63; i < L; i += 64) {
     if (first[base + i] != kMaybeFirst) continue;
     const uint64_t mine = ent[base + i].x, r = ht[e_slot[base + i]].val;
@@ -768,7 +770,10 @@ k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
       if (lm != (r & ((1ull << kRepLenBits) - 1)) || diff_global_wide(text + (mine >> kRepLenBits), text + (r >> kRepLenBits), (uint32_t)lm)) *collision = 1;
     }
     first[base + i] = f;
+    mine_cnt += f;
   }
+  mine_cnt = wave_reduce_u32(mine_cnt);
+  if ((threadIdx.x & 63) == 0) tile_firsts[tile] = mine_cnt;
 }
 
 // The representatives get their ids (their rank among the representatives, i.e. ids grow with the place of a
@@ -776,19 +781,27 @@ k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
 __global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
 k_entry_assign(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
                const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot, const uint8_t* __restrict__ first,
-               const uint32_t* __restrict__ first_scan, DictSlot* __restrict__ ht, uint32_t* __restrict__ term_len,
-               uint64_t* __restrict__ term_src) {
+               const uint32_t* __restrict__ firsts_before /*[tile]: representatives in the tiles before it*/, DictSlot* __restrict__ ht,
+               uint32_t* __restrict__ term_len, uint64_t* __restrict__ term_src) {
   const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
   const uint64_t base = 3ull * tile_first[tile];
   const uint32_t L = tile_leaders[tile];
-  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) {
-    if (!first[base + i]) continue;
-    const uint32_t id = first_scan[base + i];
-    const uint64_t rep = ent[base + i].x;
-    ht[e_slot[base + i]].val = id;
-    term_len[id] = (uint32_t)(rep & ((1ull << kRepLenBits) - 1));
-    term_src[id] = rep >> kRepLenBits;
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t run = firsts_before[tile];
+  for (uint32_t i0 = 0; i0 < L; i0 += 64) {  // wave-uniform trip count: the ballot sees all 64 lanes
+    const uint32_t i = i0 + lane;
+    const bool f = i < L && first[base + i];
+    const uint64_t b = __ballot(f);
+    if (f) {
+      const uint32_t id = run + (uint32_t)__popcll(b & lt);
+      const uint64_t rep = ent[base + i].x;
+      ht[e_slot[base + i]].val = id;
+      term_len[id] = (uint32_t)(rep & ((1ull << kRepLenBits) - 1));
+      term_src[id] = rep >> kRepLenBits;
+    }
+    run += (uint32_t)__popcll(b);
   }
 }
 
@@ -1538,6 +1551,45 @@ struct StageTimer {
 const char* const kStageNames[12] = {"line_scan", "tokenise_hash", "dictionary", "string_pool", "vertex_masks", "sort_triples",
                                      "place", "split_partitions", "node_index", "vp_index", "dict_clear_kernel", "dict_claim_kernel"};
 
+// One block writes a batch of small device results into the pinned host block and then the batch's number into the
+// pinned word the host watches (HostFetch, batched mode).
+__global__ void __launch_bounds__(256)
+k_fetch_batch(FetchBatch b, uint8_t* __restrict__ host, unsigned long long* __restrict__ host_seq, unsigned long long seq) {
+  for (int k = 0; k < b.n; ++k) {
+    const uint8_t* src = static_cast<const uint8_t*>(b.src[k]);
+    uint8_t* dst = host + b.off[k];
+    const uint32_t bytes = b.bytes[k];
+    if (((reinterpret_cast<uintptr_t>(src) | bytes) & 3) == 0) {  // dst offsets are multiples of 16
+      for (uint32_t i = threadIdx.x; i < bytes / 4; i += 256)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(dst) + i, reinterpret_cast<const uint32_t*>(src)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      for (uint32_t i = threadIdx.x; i < bytes; i += 256)
+        __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_fetch_batch(dx_ctx* ctx, const FetchBatch& b, unsigned long long seq) {
+  hipLaunchKernelGGL(k_fetch_batch, dim3(1), dim3(256), 0, ctx->stream, b, ctx->part_host_dev, ctx->fetch_seq_dev, seq);
+}
+
+// Watches the pinned word for a while, then waits through the stream (which also reports a failed kernel).
+void wait_fetch_seq(dx_ctx* ctx, unsigned long long seq) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const volatile unsigned long long* w = ctx->fetch_seq;
+  for (uint32_t i = 0;; ++i) {
+    if (*w >= seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+    __builtin_ia32_pause();
+    if ((i & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+  }
+  DX_HIP(hipStreamSynchronize(ctx->stream));
+  DX_HIP(hipGetLastError());
+  if (*w < seq) throw DxError(DX_E_HIP, "the partitioner's results did not arrive on the host");
+}
+
 void dict_build_table(dx_ctx* ctx) {
   Dictionary& d = ctx->dict;
   hipStream_t s = ctx->stream;
@@ -1894,7 +1946,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   st.n_bytes = n_bytes;
   StageTimer tm(ctx);
   ctx->part_host_used = 0;
-  HostFetch fetch(ctx);
+  HostFetch fetch(ctx, /*batch=*/true);  // every device buffer handed to fetch.add() below lives until the next fetch.sync()
 
   // ---- 1. record starts
   const unsigned ntiles = (unsigned)((n_bytes + LS_TILE - 1) / LS_TILE);
@@ -1929,7 +1981,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   while (cap < n_rec / 2) cap <<= 1;
   DevBuf<DictSlot> ht(pool, cap);
   DevBuf<uint8_t> first(pool, n_occ);
-  DevBuf<uint32_t> first_scan(pool, n_occ);
+  DevBuf<uint32_t> tile_firsts(pool, ntiles + 1);  // representatives per tile, then (scanned) before each tile
   DevBuf<uint32_t> coll(pool, 2);  // [0] true hash collision, [1] table overflow
   uint64_t seed = 0x243F6A8885A308D3ull;
   uint32_t n_terms = 0;
@@ -1954,8 +2006,10 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     DX_HIP(hipEventRecord(e3, s));
     if (n_rec)
       hipLaunchKernelGGL(k_entry_first, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, text,
-                         ent.p, e_slot.p, ht.p, first.p, coll.p);
-    exclusive_scan_u8_u32(pool, first.p, first_scan.p, n_occ, d_total.p, s);
+                         ent.p, e_slot.p, ht.p, first.p, tile_firsts.p, coll.p);
+    if (n_rec) DX_HIP(hipMemsetAsync(tile_firsts.p + ntiles, 0, 4, s));
+    if (n_rec) exclusive_scan_u32_u32(pool, tile_firsts.p, tile_firsts.p, (size_t)ntiles + 1, d_total.p, s);
+    else DX_HIP(hipMemsetAsync(d_total.p, 0, 4, s));
     if (n_rec) hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, s, tile_leaders.p, ntiles, d_total.p + 1);
     unsigned long long h_err = ~0ull;
     uint32_t h_coll[2] = {0, 0};
@@ -1964,6 +2018,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     fetch.add(&n_terms, d_total.p, 4);
     if (n_rec) fetch.add(&st.n_dict_entries, d_total.p + 1, 4);
     fetch.sync();
+    DX_HIP(hipEventSynchronize(e3));  // passed on the device already (the results behind it are here); the runtime has to see it too
     DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_claim, e2, e3));
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
@@ -1994,7 +2049,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
     hipLaunchKernelGGL(k_entry_assign, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, ent.p,
-                       e_slot.p, first.p, first_scan.p, ht.p, term_len.p, term_src.p);
+                       e_slot.p, first.p, tile_firsts.p, ht.p, term_len.p, term_src.p);
     hipLaunchKernelGGL(k_entry_to_id, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, ht.p, e_slot.p);
     hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_entry.p, e_slot.p, kind.p, n_rec, S.p, P.p, O.p,
                        fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
@@ -2005,7 +2060,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   d.ht = std::move(ht);
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
-  t_entry.reset(); e_slot.reset(); first.reset(); first_scan.reset();
+  t_entry.reset(); e_slot.reset(); first.reset(); tile_firsts.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
@@ -2079,6 +2134,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
       fetch.upload(dmask.p, masks.data(), classes.size() * 8);
       hipLaunchKernelGGL(k_set_class_masks, dim3(blocks(classes.size())), dim3(256), 0, s, dids.p, dmask.p, (uint32_t)classes.size(), Pm.p);
     }
+    fetch.flush();  // dids ends here
   }
   if (n_rec) hipLaunchKernelGGL(k_vertex_masks, dim3(blocks(n_rec)), dim3(256), 0, s, S.p, O.p, kind.p, n_rec, Pm.p, M.p);
   if (sharded && n_terms) {
@@ -2267,6 +2323,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * np)), dim3(256), 0, s, d.pool.p, d_pred_src.p, d_pred_off.p, (uint64_t)np, packed.p);
     pred_bytes.resize(pred_off[np]);
     fetch.add(&pred_bytes[0], packed.p, pred_off[np]);
+    fetch.flush();  // packed ends here
   }
   std::vector<uint32_t> h_tstart;
   {
@@ -2276,6 +2333,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     if (n_rows) hipLaunchKernelGGL(k_table_starts, dim3(std::min(blocks(n_rows, 1024), 2048u)), dim3(256), 0, s, ps.row_p.p, d_part_base.p, nparts, np, tstart.p);
     h_tstart.resize(nt);
     fetch.add(h_tstart.data(), tstart.p, nt * 4);  // wanted at the very end: comes back with a later synchronisation
+    fetch.flush();  // tstart ends here
   }
   tm.mark();
 
@@ -2357,6 +2415,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     DevBuf<uint32_t> vb(pool, nparts + 1);
     hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, n_o, bits_term + 1 + bits_pred, nparts, vb.p);
     fetch.add(hvb.data(), vb.p, (nparts + 1) * 4);
+    fetch.flush();  // vb ends here
     st.n_vp_index = (uint64_t)n_s + n_o;
   }
   tm.mark();
@@ -2392,6 +2451,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     st.n_tables = (uint32_t)ps.tables.size();
   }
   // ---- stage times
+  DX_HIP(hipEventSynchronize(tm.ev.back()));  // passed on the device before the last results left it
   std::vector<float> gaps;
   for (size_t i = 1; i < tm.ev.size(); ++i) {
     float ms = 0;

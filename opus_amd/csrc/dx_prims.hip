@@ -250,21 +250,30 @@ void exclusive_scan_u32_u64(DevPool& pool, const uint32_t* in, uint64_t* out, si
 }
 
 // ---- radix sort ----------------------------------------------------------------------------------
-// 8-bit digits, least significant first. Per pass: (1) per-tile digit histogram in LDS, (2) scan of
-// the [digit][tile] matrix, (3) scatter. A tile is 4096 keys; each of the 4 waves of a block owns a
-// contiguous 1024-key quarter, so (wave, round, lane) order equals key order and ranking by wave-level
-// ballots keeps the sort stable. (Sixteen keys per lane: 13 M 8-byte keys sort in 0.81 ms; eight per lane
-// 0.84 ms -- twice the tiles to scan, runs half as long in the scatter --, thirty-two 0.97 ms.)
+// Digits of 8 bits, least significant first. Per pass: (1) per-tile digit histogram in LDS, (2) scan of the [digit][tile] matrix, (3) scatter. A tile is
+// 4096 keys; each of the 4 waves of a block owns a contiguous 1024-key quarter, so (wave, round, lane) order equals
+// key order and ranking by wave-level ballots keeps the sort stable. (Sixteen keys per lane: eight per lane means
+// twice the tiles to scan and runs half as long in the scatter, thirty-two too many registers.)
 constexpr int RS_THREADS = 256;
 constexpr int RS_KPT = 16;
 constexpr int RS_TILE = RS_THREADS * RS_KPT;
-constexpr int RS_RADIX = 256;
+
+// Which tile a block works on. A row of the [digit][tile] count matrix holds sixteen tiles' counts per 64 bytes; blocks
+// whose numbers are equal modulo 8 share a second-level cache, so inside every run of 128 block numbers the sixteen
+// blocks of one such class take sixteen neighbouring tiles: their 4-byte counts meet in one cache and leave it as one
+// line instead of sixteen partial ones (and come back the same way in the scatter). The last, partial run maps 1:1.
+__device__ __forceinline__ unsigned rs_tile_of(unsigned b, unsigned ntiles) {
+  if (b >= (ntiles & ~127u)) return b;
+  const unsigned r = b & 127u;
+  return (b & ~127u) + ((r & 7u) << 4) + (r >> 3);
+}
 
 // lanes of the wave whose digit equals this lane's (among the lanes with `valid`)
+template <int BITS>
 __device__ __forceinline__ uint64_t digit_peers(uint32_t d, bool valid) {
   uint64_t peers = __ballot(valid);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < BITS; ++b) {
     const bool bit = (d >> b) & 1;
     const uint64_t m = __ballot(bit);
     peers &= bit ? m : ~m;
@@ -290,39 +299,60 @@ __device__ __forceinline__ void load_keys(const K* __restrict__ keys, size_t fir
 // Keys that arrive sorted by another field (the rows of one predicate, one after another) put all 64 lanes of a
 // wave on one counter, and LDS serialises those: the lanes of a wave that share a digit add their number once.
 // (Counting four tiles per block, to write the [digit][tile] matrix in 16-byte pieces, measured no faster.)
-template <typename K>
+template <typename K, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
-k_rs_hist(const K* __restrict__ keys, size_t n, int shift, uint32_t* __restrict__ tile_hist, unsigned ntiles) {
-  __shared__ uint32_t hist[RS_RADIX];
-  hist[threadIdx.x] = 0;
+k_rs_hist(const K* __restrict__ keys, size_t n, int shift, uint32_t* __restrict__ tile_hist, size_t stride, unsigned ntiles) {
+  constexpr int R = 1 << BITS;
+  __shared__ uint32_t hist[R];
+  for (int d = threadIdx.x; d < R; d += RS_THREADS) hist[d] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const size_t first = (size_t)blockIdx.x * RS_TILE + threadIdx.x;
+  const unsigned tile = rs_tile_of(blockIdx.x, ntiles);
+  const size_t first = (size_t)tile * RS_TILE + threadIdx.x;
   K k[RS_KPT];
   load_keys(keys, first, RS_THREADS, n, k);
 #pragma unroll
   for (int j = 0; j < RS_KPT; ++j) {
     const bool valid = first + (size_t)j * RS_THREADS < n;
-    const uint32_t d = (uint32_t)(k[j] >> shift) & 0xFF;
-    const uint64_t peers = digit_peers(d, valid);
-    if (valid && (peers & lt) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
+    const uint32_t d = (uint32_t)(k[j] >> shift) & (R - 1);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+    if (__all(valid && d == d0)) {
+      if (lane == 0) atomicAdd(&hist[d0], 64u);
+    } else if (valid) {
+      atomicAdd(&hist[d], 1u);
+    }
   }
   __syncthreads();
-  tile_hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+  for (int d = threadIdx.x; d < R; d += RS_THREADS) {
+    tile_hist[(size_t)d * stride + tile] = hist[d];
+    if (tile == ntiles - 1)  // the padding of the rows takes part in the scan of the matrix
+      for (size_t c = ntiles; c < stride; ++c) tile_hist[(size_t)d * stride + c] = 0;
+  }
 }
 
-template <typename K, bool HAS_VALS>
+// Keys whose size allows it leave the tile through LDS: ranked keys are first put in the tile's sorted order there,
+// then thread t writes elements t, t + 256, ..., so that the lanes of a wave write neighbouring addresses of a
+// digit's run (8 or 16 keys per digit and tile) instead of 64 separate 4- or 8-byte pieces per store instruction.
+template <typename K, bool HAS_VALS, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
 k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
-             uint32_t* __restrict__ vout, size_t n, int shift, const uint32_t* __restrict__ tile_off, unsigned ntiles) {
-  __shared__ uint32_t whist[4][RS_RADIX];
+             uint32_t* __restrict__ vout, size_t n, int shift, const uint32_t* __restrict__ tile_off, size_t stride, unsigned ntiles) {
+  constexpr bool kStaged = sizeof(K) <= 8;
+  constexpr int R = 1 << BITS;
+  constexpr int kDigitsPerThread = R / RS_THREADS;  // thread t looks after digits t * kDigitsPerThread ...
+  __shared__ uint32_t whist[4][R];
+  __shared__ uint32_t gbase[kStaged ? R : 1];
+  __shared__ uint32_t scan_lds[8];
+  __shared__ K stage[kStaged ? RS_TILE : 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned tile = rs_tile_of(blockIdx.x, ntiles);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) whist[i][threadIdx.x] = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int d = threadIdx.x; d < R; d += RS_THREADS) whist[i][d] = 0;
   __syncthreads();
 
-  const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_KPT);
+  const size_t wbase = (size_t)tile * RS_TILE + (size_t)w * (64 * RS_KPT);
   K k[RS_KPT];
   uint32_t v[RS_KPT];
   uint32_t rank[RS_KPT];
@@ -333,8 +363,8 @@ k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __r
   for (int j = 0; j < RS_KPT; ++j) {
     const size_t i = wbase + (size_t)j * 64 + lane;
     const bool valid = i < n;
-    const uint32_t d = (uint32_t)(k[j] >> shift) & 0xFF;
-    const uint64_t peers = digit_peers(d, valid);
+    const uint32_t d = (uint32_t)(k[j] >> shift) & (R - 1);
+    const uint64_t peers = digit_peers<BITS>(d, valid);
     // lanes of one wave run in lockstep: every peer reads the counter before the leader bumps it
     uint32_t old = 0;
     if (valid) old = whist[w][d];
@@ -345,25 +375,81 @@ k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __r
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  {  // thread t turns the four wave counts of digit t into output bases
-    const int d = threadIdx.x;
-    uint32_t run = tile_off[(size_t)d * ntiles + blockIdx.x];
+  if constexpr (!kStaged) {
+    // a thread turns the four wave counts of its digits into output bases
+    for (int d = threadIdx.x; d < R; d += RS_THREADS) {
+      uint32_t run = tile_off[(size_t)d * stride + tile];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t c = whist[i][d];
-      whist[i][d] = run;
-      run += c;
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t c = whist[i][d];
+        whist[i][d] = run;
+        run += c;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < RS_KPT; ++j) {
-    const size_t i = wbase + (size_t)j * 64 + lane;
-    if (i < n) {
-      const uint32_t d = (uint32_t)(k[j] >> shift) & 0xFF;
-      const uint32_t pos = whist[w][d] + rank[j];
-      kout[pos] = k[j];
-      if (HAS_VALS) vout[pos] = v[j];
+    for (int j = 0; j < RS_KPT; ++j) {
+      const size_t i = wbase + (size_t)j * 64 + lane;
+      if (i < n) {
+        const uint32_t d = (uint32_t)(k[j] >> shift) & (R - 1);
+        const uint32_t pos = whist[w][d] + rank[j];
+        kout[pos] = k[j];
+        if (HAS_VALS) vout[pos] = v[j];
+      }
+    }
+  } else {
+    {  // where each digit's run begins inside the tile, and what to add to a tile position to get the output position
+      uint32_t c[kDigitsPerThread][4], mine = 0;
+#pragma unroll
+      for (int q = 0; q < kDigitsPerThread; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[q][i] = whist[i][threadIdx.x * kDigitsPerThread + q]; mine += c[q][i]; }
+      uint32_t total;
+      uint32_t run = block_excl_scan_256<uint32_t>(mine, scan_lds, total);
+#pragma unroll
+      for (int q = 0; q < kDigitsPerThread; ++q) {
+        const int d = threadIdx.x * kDigitsPerThread + q;
+        gbase[d] = tile_off[(size_t)d * stride + tile] - run;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { whist[i][d] = run; run += c[q][i]; }
+      }
+    }
+    __syncthreads();
+    uint32_t lp[RS_KPT];
+#pragma unroll
+    for (int j = 0; j < RS_KPT; ++j) {
+      const size_t i = wbase + (size_t)j * 64 + lane;
+      const uint32_t d = (uint32_t)(k[j] >> shift) & (R - 1);
+      lp[j] = whist[w][d] + rank[j];
+      if (i < n) stage[lp[j]] = k[j];
+    }
+    __syncthreads();
+    const size_t left = n - (size_t)tile * RS_TILE;
+    const uint32_t cnt = left < (size_t)RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
+    uint32_t gp[RS_KPT];
+#pragma unroll
+    for (int j = 0; j < RS_KPT; ++j) {
+      const uint32_t i = (uint32_t)j * RS_THREADS + threadIdx.x;
+      if (i < cnt) {
+        const K key = stage[i];
+        gp[j] = gbase[(uint32_t)(key >> shift) & (R - 1)] + i;
+        kout[gp[j]] = key;
+      }
+    }
+    if constexpr (HAS_VALS) {
+      uint32_t* vstage = reinterpret_cast<uint32_t*>(stage);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RS_KPT; ++j) {
+        const size_t i = wbase + (size_t)j * 64 + lane;
+        if (i < n) vstage[lp[j]] = v[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RS_KPT; ++j) {
+        const uint32_t i = (uint32_t)j * RS_THREADS + threadIdx.x;
+        if (i < cnt) vout[gp[j]] = vstage[i];
+      }
     }
   }
 }
@@ -372,25 +458,25 @@ k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __r
 // given (it must be the pool allocation `keys` points at, with n elements) and the result ends in the scratch
 // array, the two allocations change places instead of being copied (an odd number of passes over 13 M keys
 // would otherwise end with a 100 MB copy).
-template <typename K>
-static void radix_sort_impl(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
-  if (n < 2 || key_bits <= 0) return;
-  if (n >= (1ull << 32)) throw DxError(DX_E_RANGE, "radix_sort_u64: more than 2^32 keys");
+template <typename K, int BITS>
+static void radix_sort_passes(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
+  constexpr int R = 1 << BITS;
   const unsigned ntiles = (unsigned)((n + RS_TILE - 1) / RS_TILE);
   DevBuf<K> ktmp(pool, keys_buf ? keys_buf->n : n);
   DevBuf<uint32_t> vtmp(pool, vals ? n : 1);
-  DevBuf<uint32_t> hist(pool, (size_t)RS_RADIX * ntiles);
+  const size_t stride = ((size_t)ntiles + 15) & ~(size_t)15;  // rows of the count matrix begin on 64-byte boundaries
+  DevBuf<uint32_t> hist(pool, (size_t)R * stride);
+  const int passes = (key_bits + BITS - 1) / BITS;
   K* kin = keys; K* kout = ktmp.p;
   uint32_t* vin = vals; uint32_t* vout = vtmp.p;
-  const int passes = (key_bits + 7) / 8;
   for (int p = 0; p < passes; ++p) {
-    const int shift = p * 8;
-    hipLaunchKernelGGL(k_rs_hist<K>, dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, hist.p, ntiles);
-    exclusive_scan_u32_u32(pool, hist.p, hist.p, (size_t)RS_RADIX * ntiles, nullptr, s);
+    const int shift = p * BITS;
+    hipLaunchKernelGGL((k_rs_hist<K, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, hist.p, stride, ntiles);
+    exclusive_scan_u32_u32(pool, hist.p, hist.p, (size_t)R * stride, nullptr, s);
     if (vals)
-      hipLaunchKernelGGL((k_rs_scatter<K, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, ntiles);
+      hipLaunchKernelGGL((k_rs_scatter<K, true, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, stride, ntiles);
     else
-      hipLaunchKernelGGL((k_rs_scatter<K, false>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, ntiles);
+      hipLaunchKernelGGL((k_rs_scatter<K, false, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, stride, ntiles);
     std::swap(kin, kout);
     std::swap(vin, vout);
   }
@@ -403,6 +489,17 @@ static void radix_sort_impl(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_
       if (vals) DX_HIP(hipMemcpyAsync(vals, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
   }
+}
+
+template <typename K>
+static void radix_sort_impl(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
+  if (n < 2 || key_bits <= 0) return;
+  if (n >= (1ull << 32)) throw DxError(DX_E_RANGE, "radix_sort_u64: more than 2^32 keys");
+  // 8-bit digits. (9-bit digits would sort 49-bit keys in six passes instead of seven, but the runs a tile writes per
+  // digit halve and a ninth ballot joins every ranking step: 0.67 ms against 0.62 ms for 13 M keys. One launch that
+  // scans the matrix row by row, the rows exchanging their sums through flagged words, measured 12 us against the
+  // 10 us of the two launches of the plain scan.)
+  radix_sort_passes<K, 8>(pool, keys, keys_buf, vals, n, key_bits, s);
 }
 
 void radix_sort_u64(DevPool& pool, uint64_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {

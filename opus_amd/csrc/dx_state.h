@@ -143,7 +143,11 @@ struct dx_ctx {
   bool q_counters_dirty = false;        // a statement failed between its first and its last kernel: clear before the next
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
   uint8_t* part_host = nullptr;         // pinned block the partitioner's small results come back through
+  uint8_t* part_host_dev = nullptr;     // the same block as the device addresses it
   size_t part_host_used = 0;
+  unsigned long long* fetch_seq = nullptr;      // pinned word: number of the last batch of small results that has landed
+  unsigned long long* fetch_seq_dev = nullptr;
+  uint64_t fetch_seq_next = 0;
   // this GPU's copy of the file-scope scratch array behind dx_query_count_noalloc (address looked up in dx_init)
   void* noalloc_scratch = nullptr;
   size_t noalloc_scratch_bytes = 0;
@@ -159,38 +163,79 @@ namespace dx {
 // after a synchronisation that has happened anyway. The block is handed out from its start again at every
 // partition call; what does not fit is copied the slow way.
 constexpr size_t kPartHostBytes = 256 << 10;
+// Batched mode (the partitioner): small results are not copied one by one (a copy engine transfer or a copy kernel
+// each, ~6 us apiece with its gap) but written into the pinned block by ONE kernel per batch, which then stores the
+// batch's number into a pinned word; sync() watches that word instead of waiting for the stream's completion signal
+// (whose wake-up costs ~10 us more). A batch is queued by flush() or sync(): the device buffers named by add() must
+// live until then.
+constexpr int kFetchBatch = 8;
+constexpr size_t kFetchSmall = 8 << 10;
+struct FetchBatch {
+  const void* src[kFetchBatch];
+  uint32_t off[kFetchBatch], bytes[kFetchBatch];
+  int n;
+};
+void launch_fetch_batch(dx_ctx* ctx, const FetchBatch& b, unsigned long long seq);  // dx_hp1.hip
+void wait_fetch_seq(dx_ctx* ctx, unsigned long long seq);                            // dx_hp1.hip
 struct HostFetch {
   dx_ctx* ctx;
   struct Item { void* dst; size_t off, bytes; };
   std::vector<Item> items;
-  explicit HostFetch(dx_ctx* c) : ctx(c) {}
+  bool batched;
+  FetchBatch pending{};
+  unsigned long long last_seq = 0;  // the batch queued last, 0: something else was queued after it (or nothing at all)
+  explicit HostFetch(dx_ctx* c, bool batch = false) : ctx(c), batched(batch) { pending.n = 0; }
+  void ensure_block() {
+    if (ctx->part_host) return;
+    void* p = nullptr;
+    DX_HIP(hipHostMalloc(&p, kPartHostBytes, hipHostMallocDefault));
+    ctx->part_host = static_cast<uint8_t*>(p);
+    ctx->part_host_used = 0;
+    void* d = nullptr;
+    DX_HIP(hipHostGetDevicePointer(&d, p, 0));
+    ctx->part_host_dev = static_cast<uint8_t*>(d);
+    DX_HIP(hipHostMalloc(&p, 64, hipHostMallocDefault));
+    ctx->fetch_seq = static_cast<unsigned long long*>(p);
+    *ctx->fetch_seq = 0;
+    DX_HIP(hipHostGetDevicePointer(&d, p, 0));
+    ctx->fetch_seq_dev = static_cast<unsigned long long*>(d);
+  }
   void add(void* dst, const void* dev, size_t bytes) {
     if (!bytes) return;
-    if (!ctx->part_host) {
-      void* p = nullptr;
-      DX_HIP(hipHostMalloc(&p, kPartHostBytes, hipHostMallocDefault));
-      ctx->part_host = static_cast<uint8_t*>(p);
-      ctx->part_host_used = 0;
-    }
+    ensure_block();
     const size_t off = (ctx->part_host_used + 15) & ~(size_t)15;
     if (off + bytes > kPartHostBytes) {
+      flush();
       DX_HIP(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      last_seq = 0;
       return;
     }
-    DX_HIP(hipMemcpyAsync(ctx->part_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ctx->part_host_used = off + bytes;
     items.push_back({dst, off, bytes});
+    if (batched && bytes <= kFetchSmall) {
+      if (pending.n == kFetchBatch) flush();
+      pending.src[pending.n] = dev;
+      pending.off[pending.n] = (uint32_t)off;
+      pending.bytes[pending.n] = (uint32_t)bytes;
+      ++pending.n;
+      return;
+    }
+    flush();  // keeps the order of the stream: what was asked for first lands first
+    DX_HIP(hipMemcpyAsync(ctx->part_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    last_seq = 0;
+  }
+  // queues the batch collected so far
+  void flush() {
+    if (!pending.n) return;
+    last_seq = ++ctx->fetch_seq_next;
+    launch_fetch_batch(ctx, pending, last_seq);
+    pending.n = 0;
   }
   // Host to device through the same pinned block: the bytes are copied into it now (the caller's memory is free
   // again at once) and travel with the stream; a copy from pageable memory is staged by the runtime call by call.
   void upload(void* dev, const void* src, size_t bytes) {
     if (!bytes) return;
-    if (!ctx->part_host) {
-      void* p = nullptr;
-      DX_HIP(hipHostMalloc(&p, kPartHostBytes, hipHostMallocDefault));
-      ctx->part_host = static_cast<uint8_t*>(p);
-      ctx->part_host_used = 0;
-    }
+    ensure_block();
     const size_t off = (ctx->part_host_used + 15) & ~(size_t)15;
     if (off + bytes > kPartHostBytes) {
       DX_HIP(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -206,7 +251,10 @@ struct HostFetch {
     items.clear();
   }
   void sync() {
-    DX_HIP(hipStreamSynchronize(ctx->stream));
+    flush();
+    if (last_seq) wait_fetch_seq(ctx, last_seq);  // the stream is in order: everything queued before the batch has landed too
+    else DX_HIP(hipStreamSynchronize(ctx->stream));
+    last_seq = 0;
     collect();
   }
 };
