@@ -331,14 +331,15 @@ k_rs_hist(const K* __restrict__ keys, size_t n, int shift, uint32_t* __restrict_
   }
 }
 
-// Keys whose size allows it leave the tile through LDS: ranked keys are first put in the tile's sorted order there,
+// 8-byte keys leave the tile through LDS (4-byte keys gain nothing from it: measured 47 us staged against 42 us direct
+// per pass of the VP index's entries; 16-byte keys would need 64 KiB): ranked keys are first put in the tile's sorted order there,
 // then thread t writes elements t, t + 256, ..., so that the lanes of a wave write neighbouring addresses of a
 // digit's run (8 or 16 keys per digit and tile) instead of 64 separate 4- or 8-byte pieces per store instruction.
 template <typename K, bool HAS_VALS, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
 k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __restrict__ kout,
              uint32_t* __restrict__ vout, size_t n, int shift, const uint32_t* __restrict__ tile_off, size_t stride, unsigned ntiles) {
-  constexpr bool kStaged = sizeof(K) <= 8;
+  constexpr bool kStaged = sizeof(K) == 8;
   constexpr int R = 1 << BITS;
   constexpr int kDigitsPerThread = R / RS_THREADS;  // thread t looks after digits t * kDigitsPerThread ...
   __shared__ uint32_t whist[4][R];
