@@ -457,11 +457,11 @@ def main():
         n_rec, n_occ = st.n_triples, 3 * st.n_triples
         n_ent = int(st.n_dict_entries)                          # occurrences left after the folding inside the tiles
         kernels = {
-            # one pass over the text: the text itself and its 2-byte record-start mask per 16 bytes read; per record the
-            # three occurrences' entry numbers (12 B) and the kind (1 B) written; per dictionary entry its span and
-            # its hash (16 B) written
-            "k_tokenise (text -> term spans, hashes, terms of a tile folded onto their first occurrence there)":
-                (stage_avg["tokenise_hash"], n_bytes + n_bytes // 8 + 13 * n_rec + 16 * n_ent),
+            # one pass over the text: the text itself read (and, when the line scan ran as a pass of its own, its 2-byte
+            # record-start mask per 16 bytes); per record the three occurrences' entry numbers (12 B) and the kind (1 B)
+            # written; per dictionary entry its span and its hash (16 B) written
+            "k_tokenise (text -> record starts, term spans, hashes, terms of a tile folded onto their first occurrence there)":
+                (stage_avg["tokenise_hash"], n_bytes + (n_bytes // 8 if stage_avg["line_scan"] > 0 else 0) + 13 * n_rec + 16 * n_ent),
             "k_ht_clear (16-byte slots)":
                 (stage_avg["dict_clear_kernel"], 16 * (1 << max(10, math.ceil(math.log2(max(n_rec // 2, 1)))))),
             # per entry: span and hash read (16 B), its 16-byte slot read, the slot's number written (4 B)

@@ -459,23 +459,81 @@ __device__ __forceinline__ void stage_window(uint32_t* win, const uint8_t* __res
 // at the tile's own place, [3 * first_rec, 3 * first_rec + leaders): entry indices grow with the position in
 // the text. Only those entries go to the table in HBM afterwards (k_entry_claim), in a kernel without the
 // window in LDS and therefore at full occupancy. Two different terms in one bucket just make two leaders.
+//
+// FUSED: the block also finds the record starts of its tile itself (the rule of k_line_scan, applied to the staged
+// window), so the text is read from HBM once instead of twice. The index of a tile's first record is then not
+// known when the tile is tokenised: the tile's records and entries go to a place of their own, slots
+// [tile * slots_per_tile, + records of the tile), and are packed once the counts have been scanned (k_encode_tiles).
+// A tile with more records than slots reports overflow, and the caller falls back to the two-pass form.
+constexpr uint32_t kSlotsPerTile = 512;  // 64 bytes per record on average inside a tile; LUBM lines average 178
+
+// Record starts among the 16 bytes of a chunk (see k_line_scan for the rule): `tin` / `lin` are the terminator / LF
+// flags of the word before the chunk. Empty lines are reported through err.
+__device__ __forceinline__ uint32_t chunk_starts(const uint32_t (&w)[4], uint32_t tin, uint32_t lin, uint32_t keep, uint64_t i0,
+                                                 unsigned long long* __restrict__ err) {
+  uint32_t L[4], R[4], T[4], H[4], S[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    L[d] = eq_mask(w[d], 0x0A0A0A0Au);
+    R[d] = eq_mask(w[d], 0x0D0D0D0Du);
+    H[d] = eq_mask(w[d], 0x23232323u);
+    T[d] = L[d] | R[d];
+  }
+  uint32_t tp = tin, pair = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);
+    S[d] = Tp & ~(T[d] | H[d]);
+    pair |= Tp & T[d];
+    tp = T[d];
+  }
+  const uint32_t m16 = (flags_to_nibble(S[0]) | (flags_to_nibble(S[1]) << 4) | (flags_to_nibble(S[2]) << 8) | (flags_to_nibble(S[3]) << 12)) & keep;
+  if (pair) {
+    uint32_t E[4];
+    uint32_t lp = lin;
+    tp = tin;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);
+      const uint32_t Lp = __builtin_amdgcn_alignbit(L[d], lp, 24);
+      E[d] = (Lp & T[d]) | ((Tp & ~Lp) & R[d]);  // LF then terminator, or CR then CR
+      tp = T[d];
+      lp = L[d];
+    }
+    const uint32_t e16 =
+        (flags_to_nibble(E[0]) | (flags_to_nibble(E[1]) << 4) | (flags_to_nibble(E[2]) << 8) | (flags_to_nibble(E[3]) << 12)) & keep;
+    if (e16) atomicMin(err, (unsigned long long)(i0 + __ffs((int)e16) - 1));
+  }
+  return m16;
+}
+
+template <bool FUSED>
 __global__ void __launch_bounds__(TK_THREADS)
-k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask,
-           const uint32_t* __restrict__ tile_first /*scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash, uint64_t n_rec,
+k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ chunk_mask /*two-pass form*/,
+           const uint32_t* __restrict__ tile_first /*two-pass form: scanned counts, ntiles+1*/, uint64_t seed, uint64_t type_hash,
+           uint64_t n_rec /*records, or slots in the fused form: the stride of t_entry's fields*/,
            ulonglong2* __restrict__ ent /*[entry]: x = (offset << 24) | length, y = hash*/,
            uint32_t* __restrict__ t_entry /*[field][record]: the occurrence's entry*/, uint32_t* __restrict__ tile_leaders /*[tile]*/,
-           uint8_t* __restrict__ kind, unsigned long long* __restrict__ err) {
+           uint8_t* __restrict__ kind, unsigned long long* __restrict__ err,
+           uint32_t* __restrict__ tile_counts /*fused form, out: records that start in the tile*/, uint32_t* __restrict__ overflow /*fused form*/) {
   __shared__ __attribute__((aligned(16))) uint32_t win[(TK_PRE + TK_WIN) / 4 + 8];
-  __shared__ uint32_t occ_info[3 * TK_ROUND];  // window offset | length << 16 of the round's occurrences
-  __shared__ uint32_t table[TK_BUCKETS];       // earliest occurrence per bucket; afterwards the leaders' ranks (16 bits each)
+  __shared__ __attribute__((aligned(16))) uint32_t fold_lds[3 * TK_ROUND + TK_BUCKETS];
+  uint32_t* const occ_info = fold_lds;             // window offset | length << 16 of the round's occurrences
+  uint32_t* const table = fold_lds + 3 * TK_ROUND; // earliest occurrence per bucket; afterwards the leaders' ranks (16 bits each)
   __shared__ uint16_t starts[TK_ROUND];
   __shared__ uint32_t scan_lds[8];
   const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
-  const uint32_t first_rec = tile_first[blockIdx.x];
-  const uint32_t n_here = tile_first[blockIdx.x + 1] - first_rec;
-  if (n_here == 0) {  // block-uniform
-    if (threadIdx.x == 0) tile_leaders[blockIdx.x] = 0;
-    return;
+  uint32_t first_rec, n_here;
+  if constexpr (FUSED) {
+    first_rec = blockIdx.x * kSlotsPerTile;
+    n_here = 0;
+  } else {
+    first_rec = tile_first[blockIdx.x];
+    n_here = tile_first[blockIdx.x + 1] - first_rec;
+    if (n_here == 0) {  // block-uniform
+      if (threadIdx.x == 0) tile_leaders[blockIdx.x] = 0;
+      return;
+    }
   }
   // stage [tile0 - TK_PRE, tile0 + TK_WIN) clipped to the text; bytes outside read as '\n'
   const uint64_t avail = n - tile0;
@@ -483,7 +541,7 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
   // record starts of this tile, in order. Positions are window offsets (tile byte i is at TK_PRE + i).
   const uint32_t seg = TK_PRE + threadIdx.x * LS_PER_THREAD;  // thread t owns starts at [seg, seg + 128)
   uint32_t smask[4] = {0, 0, 0, 0};  // bit i of the 128: a record starts at byte i of this thread's segment
-  {  // requested before the window is staged: the masks travel together with the text
+  if constexpr (!FUSED) {  // requested before the window is staged: the masks travel together with the text
     const uint32_t seg_tile = threadIdx.x * LS_PER_THREAD;
     if (seg_tile < win_bytes) {
       const uint4 mv = *reinterpret_cast<const uint4*>(chunk_mask + ((tile0 + seg_tile) >> 4));  // 8 chunk masks = 128 bits
@@ -491,12 +549,43 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     }
   }
   stage_window(win, text, n, tile0);
+  if constexpr (FUSED) {
+    // Chunk c of the tile (16 bytes) is looked at by thread c % 256: neighbouring lanes read neighbouring chunks, which
+    // LDS serves without bank conflicts; the 16-bit masks go through LDS to the thread that owns the chunk's segment.
+    uint16_t* cmask = reinterpret_cast<uint16_t*>(fold_lds);  // 2048 masks = 4 KiB, gone before the folding tables are used
+    const uint32_t tile_bytes = avail < (uint64_t)LS_TILE ? (uint32_t)avail : (uint32_t)LS_TILE;
+#pragma unroll
+    for (int q = 0; q < LS_TILE / 16 / TK_THREADS; ++q) {
+      const uint32_t c = q * TK_THREADS + threadIdx.x;
+      const uint32_t off = TK_PRE + c * 16;  // window offset of the chunk
+      const uint4 v = *reinterpret_cast<const uint4*>(&win[off >> 2]);
+      const uint32_t before = win[(off >> 2) - 1];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t lin = eq_mask(before, 0x0A0A0A0Au), tin = lin | eq_mask(before, 0x0D0D0D0Du);
+      const uint32_t i = c * 16;  // tile offset
+      const uint32_t keep = i + 16 <= tile_bytes ? 0xFFFFu : (i < tile_bytes ? ((1u << (tile_bytes - i)) - 1u) : 0u);
+      cmask[c] = (uint16_t)chunk_starts(w, tin, lin, keep, tile0 + i, err);
+    }
+    __syncthreads();
+    const uint4 mv = *reinterpret_cast<const uint4*>(cmask + threadIdx.x * (LS_PER_THREAD / 16));
+    smask[0] = mv.x; smask[1] = mv.y; smask[2] = mv.z; smask[3] = mv.w;
+  }
   uint32_t at0;
   {
     const uint32_t cnt = __popc(smask[0]) + __popc(smask[1]) + __popc(smask[2]) + __popc(smask[3]);
     uint32_t total;
-    at0 = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);
-    if (__syncthreads_or(total != n_here)) {  // the masks and the counts come from one kernel: cannot differ
+    at0 = block_excl_scan_256<uint32_t>(cnt, scan_lds, total);  // its barriers end the reads of the masks in LDS
+    if constexpr (FUSED) {
+      n_here = total;  // block-uniform
+      if (threadIdx.x == 0) tile_counts[blockIdx.x] = n_here;
+      if (n_here == 0 || n_here > kSlotsPerTile) {
+        if (threadIdx.x == 0) {
+          tile_leaders[blockIdx.x] = 0;
+          if (n_here) *overflow = 1;
+        }
+        return;
+      }
+    } else if (__syncthreads_or(total != n_here)) {  // the masks and the counts come from one kernel: cannot differ
       if (threadIdx.x == 0) { atomicMin(err, (unsigned long long)tile0); tile_leaders[blockIdx.x] = 0; }
       for (uint32_t lr = threadIdx.x; lr < n_here; lr += TK_THREADS) {
         const uint64_t r = (uint64_t)first_rec + lr;
@@ -894,6 +983,37 @@ k_encode(const uint32_t* __restrict__ t_entry, const uint32_t* __restrict__ e_id
   set(is_vertex, s);
   if (k == 0) { set(has_edge, s); set(is_vertex, o); set(has_edge, o); }
   else if (k == 2) set(is_literal, o);
+}
+
+// The same for the fused tokeniser's layout: the records of tile t sit in slots [t * kSlotsPerTile, + records of t) and move
+// to their dense places [rec_first[t], rec_first[t + 1]). One wave per tile.
+__global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
+k_encode_tiles(const uint32_t* __restrict__ rec_first, unsigned ntiles, const uint32_t* __restrict__ t_entry, uint64_t n_slots,
+               const uint32_t* __restrict__ e_id, const uint8_t* __restrict__ kind_slots, uint32_t* __restrict__ S, uint32_t* __restrict__ P,
+               uint32_t* __restrict__ O, uint8_t* __restrict__ kind, uint8_t* __restrict__ is_vertex, uint8_t* __restrict__ has_edge,
+               uint8_t* __restrict__ is_literal, uint8_t* __restrict__ is_pred) {
+  const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint32_t r0 = rec_first[tile], n_here = rec_first[tile + 1] - r0;
+  const uint64_t slot0 = (uint64_t)tile * kSlotsPerTile;
+  auto set = [](uint8_t* a, uint32_t id) { if (!a[id]) a[id] = 1; };
+  for (uint32_t lr = threadIdx.x & 63; lr < n_here; lr += 64) {
+    const uint64_t at = slot0 + lr;
+    const uint32_t s = e_id[t_entry[at]], p = e_id[t_entry[n_slots + at]], o = e_id[t_entry[2 * n_slots + at]];
+    const uint32_t r = r0 + lr;
+    S[r] = s; P[r] = p; O[r] = o;
+    const uint8_t k = kind_slots[at];
+    kind[r] = k;
+    set(is_pred, p);
+    set(is_vertex, s);
+    if (k == 0) { set(has_edge, s); set(is_vertex, o); set(has_edge, o); }
+    else if (k == 2) set(is_literal, o);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_iota_times(uint32_t* __restrict__ out, uint64_t n, uint32_t mult) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint32_t)i * mult;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1948,64 +2068,132 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   ctx->part_host_used = 0;
   HostFetch fetch(ctx, /*batch=*/true);  // every device buffer handed to fetch.add() below lives until the next fetch.sync()
 
-  // ---- 1. record starts
+  // ---- 1.-3. record starts, tokeniser, dictionary
   const unsigned ntiles = (unsigned)((n_bytes + LS_TILE - 1) / LS_TILE);
   DevBuf<unsigned long long> err(pool, 1);
-  DX_HIP(hipMemsetAsync(err.p, 0xFF, 8, s));
-  DevBuf<uint32_t> tile_counts(pool, ntiles + 1);
-  DevBuf<uint16_t> chunk_mask(pool, (size_t)ntiles * (LS_TILE / 16) + 64);  // one 16-bit start mask per 16 bytes of text
   DevBuf<uint32_t> d_total(pool, 4);
-  uint32_t n_rec = 0;
-  if (n_bytes) {
-    DX_HIP(hipMemsetAsync(tile_counts.p + ntiles, 0, 4, s));
-    hipLaunchKernelGGL(k_line_scan, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, err.p);
-    exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, (size_t)ntiles + 1, d_total.p, s);
-    fetch.add(&n_rec, d_total.p, 4);
-    fetch.sync();
-  }
-  st.n_triples = n_rec;
-  tm.mark();
-
-  const uint64_t n_occ = 3ull * n_rec;
-  if (n_occ >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32/3 records on one GPU");
+  DevBuf<uint32_t> coll(pool, 4);  // [0] true hash collision, [1] table overflow, [2] a tile with more records than slots
+  DevBuf<uint32_t> tile_counts(pool, ntiles + 1);   // records starting in each tile; scanned: the tile's first record
+  DevBuf<uint32_t> tile_leaders(pool, ntiles + 1);  // dictionary entries of each tile
+  DevBuf<uint32_t> tile_firsts(pool, ntiles + 1);   // representatives per tile, then (scanned) before each tile
+  DevBuf<uint32_t> slot_first;                      // fused form: where each tile's slots begin
+  DevBuf<uint16_t> chunk_mask;                      // two-pass form: one 16-bit start mask per 16 bytes of text
   // Dictionary entries: the tokeniser folds the occurrences of a tile onto their first one there, and only those
-  // (a quarter of the occurrences on LUBM) go to the table. Tile t's entries sit at [3 * first record of t, + leaders of t).
-  DevBuf<ulonglong2> ent(pool, n_occ);
-  DevBuf<uint32_t> t_entry(pool, n_occ), e_slot(pool, n_occ), tile_leaders(pool, ntiles + 1);
-  DevBuf<uint8_t> kind(pool, n_rec);
-  // Table capacity: at least half a slot per record to start with (LUBM-like data has ~0.26 distinct terms per
-  // record, so the table is at most half full and, at LUBM-100, small enough to stay in the last-level cache while
-  // the entries gather from it); a probe chain that runs too long reports overflow and the build restarts twice
-  // as large (at 8 slots per record it is at most three eighths full and chains of 2^10 do not occur).
-  uint64_t cap = 1024;
-  while (cap < n_rec / 2) cap <<= 1;
-  DevBuf<DictSlot> ht(pool, cap);
-  DevBuf<uint8_t> first(pool, n_occ);
-  DevBuf<uint32_t> tile_firsts(pool, ntiles + 1);  // representatives per tile, then (scanned) before each tile
-  DevBuf<uint32_t> coll(pool, 2);  // [0] true hash collision, [1] table overflow
+  // (a quarter of the occurrences on LUBM) go to the table. Tile t's entries sit at [3 * first slot of t, + leaders of t);
+  // the slots of a tile are its records (two-pass form) or a fixed number per tile (fused form).
+  DevBuf<ulonglong2> ent;
+  DevBuf<uint32_t> t_entry, e_slot;
+  DevBuf<uint8_t> first, kind_slots;
+  DevBuf<DictSlot> ht;
+  uint64_t cap = 0;
+  uint32_t n_rec = 0, n_terms = 0;
+  uint64_t n_slots = 0;
   uint64_t seed = 0x243F6A8885A308D3ull;
-  uint32_t n_terms = 0;
-  float ms_tok = 0, ms_clear = 0, ms_claim = 0;
+  float ms_tok = 0, ms_clear = 0, ms_claim = 0, ms_scan = 0;
   const unsigned en_blocks = (ntiles + EN_TILES_PER_BLOCK - 1) / EN_TILES_PER_BLOCK;
+  // The fused form reads the text once; it needs every tile to hold at most kSlotsPerTile records and 32-bit entry
+  // numbers over all slots. A context that met a tile with more records takes the two-pass form for its next calls.
+  // DX_TWO_PASS=1 always takes the two-pass form (how the tests reach it on ordinary inputs).
+  bool fused = ctx->part_two_pass_calls == 0 && 3ull * ntiles * kSlotsPerTile < (1ull << 32) &&
+               !(getenv("DX_TWO_PASS") && *getenv("DX_TWO_PASS") == '1');
+  if (ctx->part_two_pass_calls) --ctx->part_two_pass_calls;
+  const uint32_t* entry_first = nullptr;  // what the kernels over the tiles' entries take as "first slot of the tile"
+  bool scanned = false;
   for (;;) {
     const hipEvent_t e0 = pooled_event(ctx, 0), e1 = pooled_event(ctx, 1), e2 = pooled_event(ctx, 2), e3 = pooled_event(ctx, 3);
-    // ---- 2./3. tokenise + hash + folding inside the tiles in one pass over the text; then the tiles' entries
-    // claim their slots, and every entry that is not its term's first occurrence is compared with that one
+    DX_HIP(hipMemsetAsync(err.p, 0xFF, 8, s));
+    DX_HIP(hipMemsetAsync(coll.p, 0, 16, s));
+    const uint64_t type_hash = hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed);
+    if (!fused && !scanned && n_bytes) {
+      // two-pass form, first pass: start masks and counts; the host learns the number of records before the tokeniser runs
+      const hipEvent_t ls0 = pooled_event(ctx, 20), ls1 = pooled_event(ctx, 21);
+      chunk_mask = DevBuf<uint16_t>(pool, (size_t)ntiles * (LS_TILE / 16) + 64);
+      DX_HIP(hipEventRecord(ls0, s));
+      DX_HIP(hipMemsetAsync(tile_counts.p + ntiles, 0, 4, s));
+      hipLaunchKernelGGL(k_line_scan, dim3(ntiles), dim3(LS_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, err.p);
+      exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, (size_t)ntiles + 1, d_total.p, s);
+      DX_HIP(hipEventRecord(ls1, s));
+      fetch.add(&n_rec, d_total.p, 4);
+      fetch.sync();
+      DX_HIP(hipEventSynchronize(ls1));
+      DX_HIP(hipEventElapsedTime(&ms_scan, ls0, ls1));
+      scanned = true;
+    }
+    if (!fused) {
+      if (3ull * n_rec >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32/3 records on one GPU");
+      n_slots = n_rec;
+      entry_first = tile_counts.p;
+    } else {
+      n_slots = (uint64_t)ntiles * kSlotsPerTile;
+      if (!slot_first.p) {
+        slot_first = DevBuf<uint32_t>(pool, ntiles + 1);
+        hipLaunchKernelGGL(k_iota_times, dim3(blocks((uint64_t)ntiles + 1)), dim3(256), 0, s, slot_first.p, (uint64_t)ntiles + 1, kSlotsPerTile);
+      }
+      entry_first = slot_first.p;
+    }
+    if (ent.n != 3 * n_slots || !ent.p) {
+      ent = DevBuf<ulonglong2>(pool, 3 * n_slots);
+      t_entry = DevBuf<uint32_t>(pool, 3 * n_slots);
+      e_slot = DevBuf<uint32_t>(pool, 3 * n_slots);
+      first = DevBuf<uint8_t>(pool, 3 * n_slots);
+      kind_slots = DevBuf<uint8_t>(pool, n_slots);
+    }
+    // ---- tokenise + hash + folding inside the tiles in one pass over the text
+    DX_HIP(hipEventRecord(e1, s));
+    if (fused) {
+      if (n_bytes) {
+        DX_HIP(hipMemsetAsync(tile_counts.p + ntiles, 0, 4, s));
+        hipLaunchKernelGGL(k_tokenise<true>, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, (const uint16_t*)nullptr, (const uint32_t*)nullptr,
+                           seed, type_hash, n_slots, ent.p, t_entry.p, tile_leaders.p, kind_slots.p, err.p, tile_counts.p, coll.p + 2);
+      }
+    } else if (n_rec) {
+      hipLaunchKernelGGL(k_tokenise<false>, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed, type_hash,
+                         n_slots, ent.p, t_entry.p, tile_leaders.p, kind_slots.p, err.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    }
+    DX_HIP(hipEventRecord(e2, s));
+    if (fused) {  // the counts, scanned; the host sizes the table by the number of records
+      if (n_bytes) {
+        exclusive_scan_u32_u32(pool, tile_counts.p, tile_counts.p, (size_t)ntiles + 1, d_total.p, s);
+        uint32_t h_over = 0;
+        unsigned long long h_err = ~0ull;
+        fetch.add(&n_rec, d_total.p, 4);
+        fetch.add(&h_over, coll.p + 2, 4);
+        fetch.add(&h_err, err.p, 8);
+        fetch.sync();
+        if (h_over) {  // some tile holds more records than it has slots: this input takes the two-pass form
+          fused = false;
+          ctx->part_two_pass_calls = 8;  // the next inputs are likely to be of the same kind: do not try each of them twice
+          ent.reset();
+          continue;
+        }
+        if (h_err != ~0ull)
+          throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
+                                            " (empty line, fewer than three fields, or a term of 16 MiB or more)");
+        if (3ull * n_rec >= (1ull << 32)) throw DxError(DX_E_RANGE, "more than 2^32/3 records on one GPU");
+      }
+    }
+    // Table capacity: at least half a slot per record to start with (LUBM-like data has ~0.26 distinct terms per
+    // record, so the table is at most half full and, at LUBM-100, small enough to stay in the last-level cache while
+    // the entries gather from it); a probe chain that runs too long reports overflow and the build restarts twice
+    // as large (at 8 slots per record it is at most three eighths full and chains of 2^10 do not occur).
+    if (!cap) {
+      cap = 1024;
+      while (cap < n_rec / 2) cap <<= 1;
+    }
+    if (ht.n != cap) ht = DevBuf<DictSlot>(pool, cap);
+    // ---- the tiles' entries claim their slots, and every entry that is not its term's first occurrence is
+    // compared with that one
     DX_HIP(hipEventRecord(e0, s));
     hipLaunchKernelGGL(k_ht_clear, dim3(2048), dim3(256), 0, s, ht.p, cap);
-    DX_HIP(hipMemsetAsync(coll.p, 0, 8, s));
-    DX_HIP(hipEventRecord(e1, s));
-    if (n_rec)
-      hipLaunchKernelGGL(k_tokenise, dim3(ntiles), dim3(TK_THREADS), 0, s, text, n_bytes, chunk_mask.p, tile_counts.p, seed,
-                         hash_bytes((const uint8_t*)"<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>", kTypeLen, seed), (uint64_t)n_rec,
-                         ent.p, t_entry.p, tile_leaders.p, kind.p, err.p);
-    DX_HIP(hipEventRecord(e2, s));
-    if (n_rec)
-      hipLaunchKernelGGL(k_entry_claim, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, text, ent.p,
-                         ht.p, cap - 1, e_slot.p, first.p, coll.p);
     DX_HIP(hipEventRecord(e3, s));
+    const hipEvent_t c0 = pooled_event(ctx, 22), c1 = pooled_event(ctx, 23);
+    DX_HIP(hipEventRecord(c0, s));
     if (n_rec)
-      hipLaunchKernelGGL(k_entry_first, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, text,
+      hipLaunchKernelGGL(k_entry_claim, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, text, ent.p,
+                         ht.p, cap - 1, e_slot.p, first.p, coll.p);
+    DX_HIP(hipEventRecord(c1, s));
+    if (n_rec)
+      hipLaunchKernelGGL(k_entry_first, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, text,
                          ent.p, e_slot.p, ht.p, first.p, tile_firsts.p, coll.p);
     if (n_rec) DX_HIP(hipMemsetAsync(tile_firsts.p + ntiles, 0, 4, s));
     if (n_rec) exclusive_scan_u32_u32(pool, tile_firsts.p, tile_firsts.p, (size_t)ntiles + 1, d_total.p, s);
@@ -2018,15 +2206,14 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     fetch.add(&n_terms, d_total.p, 4);
     if (n_rec) fetch.add(&st.n_dict_entries, d_total.p + 1, 4);
     fetch.sync();
-    DX_HIP(hipEventSynchronize(e3));  // passed on the device already (the results behind it are here); the runtime has to see it too
-    DX_HIP(hipEventElapsedTime(&ms_clear, e0, e1)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_claim, e2, e3));
+    DX_HIP(hipEventSynchronize(c1));  // passed on the device already (the results behind it are here); the runtime has to see it too
+    DX_HIP(hipEventElapsedTime(&ms_clear, e0, e3)); DX_HIP(hipEventElapsedTime(&ms_tok, e1, e2)); DX_HIP(hipEventElapsedTime(&ms_claim, c0, c1));
     if (h_err != ~0ull)
       throw DxError(DX_E_MALFORMED, "malformed N-Triples input at byte " + std::to_string(h_err) +
                                         " (empty line, fewer than three fields, or a term of 16 MiB or more)");
     if (h_coll[1]) {  // table too full for its probe bound
       if (cap >= 8ull * n_rec && cap >= 4096) throw DxError(DX_E_RANGE, "dictionary: probe chains too long at 8 slots per record");
       cap <<= 1;
-      ht = DevBuf<DictSlot>(pool, cap);
       continue;
     }
     if (!h_coll[0]) break;
@@ -2034,6 +2221,10 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     seed = mix64(seed + 0x9E3779B97F4A7C15ull);
     ++st.hash_retries;
   }
+  st.n_triples = n_rec;
+  tm.mark();  // boundary of the first stage; the times of the stages up to the encode come from their own events
+  const uint64_t n_occ = 3ull * n_rec;
+  chunk_mask.reset();
   st.n_terms = n_terms;
   Dictionary& d = ctx->dict;
   d.n_terms = n_terms;
@@ -2041,6 +2232,8 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DevBuf<uint32_t> term_len(pool, (size_t)n_terms + 1);
   DevBuf<uint64_t> term_src(pool, n_terms);
   DevBuf<uint32_t> S(pool, n_rec), P(pool, n_rec), O(pool, n_rec);
+  DevBuf<uint8_t> kind;  // per record: 0 object-property triple, 1 rdf:type, 2 literal object
+  if (fused) kind = DevBuf<uint8_t>(pool, n_rec);
   ps.term_flags = DevBuf<uint8_t>(pool, ((size_t)n_terms + 4) & ~(size_t)3);
   size_t nt_pad = ((size_t)n_terms + 4) & ~(size_t)3;
   DevBuf<uint8_t> fact(pool, 4 * nt_pad);  // is_pred, is_vertex, has_edge, is_literal
@@ -2048,11 +2241,15 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DX_HIP(hipMemsetAsync(fact.p, 0, fact.bytes(), s));
   DX_HIP(hipMemsetAsync(term_len.p, 0, ((size_t)n_terms + 1) * 4, s));
   if (n_occ) {
-    hipLaunchKernelGGL(k_entry_assign, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, ent.p,
+    hipLaunchKernelGGL(k_entry_assign, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, ent.p,
                        e_slot.p, first.p, tile_firsts.p, ht.p, term_len.p, term_src.p);
-    hipLaunchKernelGGL(k_entry_to_id, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, tile_leaders.p, ntiles, ht.p, e_slot.p);
-    hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_entry.p, e_slot.p, kind.p, n_rec, S.p, P.p, O.p,
-                       fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
+    hipLaunchKernelGGL(k_entry_to_id, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, ht.p, e_slot.p);
+    if (fused)
+      hipLaunchKernelGGL(k_encode_tiles, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, ntiles, t_entry.p, n_slots, e_slot.p,
+                         kind_slots.p, S.p, P.p, O.p, kind.p, fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
+    else
+      hipLaunchKernelGGL(k_encode, dim3(blocks(n_rec)), dim3(256), 0, s, t_entry.p, e_slot.p, kind_slots.p, n_rec, S.p, P.p, O.p,
+                         fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
   }
   hipLaunchKernelGGL(k_merge_flags, dim3(blocks(n_terms)), dim3(256), 0, s, fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad,
                      n_terms, ps.term_flags.p);
@@ -2060,7 +2257,8 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   d.ht = std::move(ht);
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
-  t_entry.reset(); e_slot.reset(); first.reset(); tile_firsts.reset();
+  if (fused) kind_slots.reset(); else kind = std::move(kind_slots);  // two-pass form: the slots are the records
+  t_entry.reset(); e_slot.reset(); first.reset(); tile_firsts.reset(); slot_first.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
@@ -2458,10 +2656,10 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     DX_HIP(hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]));
     gaps.push_back(ms);
   }
-  // event layout: [0]start [1]line_scan [2]tokenise+dictionary+encode [3]pool [4]masks [5]sort [6]place [7]split [8]node [9]vpi
-  st.ms_stage[0] = gaps[0];
+  // event layout: [0]start [1]record starts+tokenise+dictionary [2]ids+encode [3]pool [4]masks [5]sort [6]place [7]split [8]node [9]vpi
+  st.ms_stage[0] = ms_scan;  // the two-pass form's first pass; the fused form has none
   st.ms_stage[1] = ms_tok;
-  st.ms_stage[2] = gaps[1] - ms_tok;
+  st.ms_stage[2] = gaps[0] + gaps[1] - ms_scan - ms_tok;
   for (int i = 3; i <= 9; ++i) st.ms_stage[i] = gaps[i - 1];
   float total = 0;
   DX_HIP(hipEventElapsedTime(&total, tm.ev.front(), tm.ev.back()));

@@ -297,7 +297,9 @@ __device__ __forceinline__ void load_keys(const K* __restrict__ keys, size_t fir
 }
 
 // Keys that arrive sorted by another field (the rows of one predicate, one after another) put all 64 lanes of a
-// wave on one counter, and LDS serialises those: the lanes of a wave that share a digit add their number once.
+// wave on one counter, and LDS serialises those: a wave whose 64 keys share the digit adds 64 once. Any other wave
+// counts with plain LDS atomics (finding the lanes that share a digit by ballots, as the scatter has to for its
+// ranks, cost more than the conflicts it saved: 25 us against 14 us per pass over 13 M keys).
 // (Counting four tiles per block, to write the [digit][tile] matrix in 16-byte pieces, measured no faster.)
 template <typename K, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
@@ -307,7 +309,6 @@ k_rs_hist(const K* __restrict__ keys, size_t n, int shift, uint32_t* __restrict_
   for (int d = threadIdx.x; d < R; d += RS_THREADS) hist[d] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const unsigned tile = rs_tile_of(blockIdx.x, ntiles);
   const size_t first = (size_t)tile * RS_TILE + threadIdx.x;
   K k[RS_KPT];

@@ -142,6 +142,7 @@ struct dx_ctx {
   std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
   bool q_counters_dirty = false;        // a statement failed between its first and its last kernel: clear before the next
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
+  int part_two_pass_calls = 0;          // calls that still skip the fused tokeniser: an input had a tile with more records than it has slots
   uint8_t* part_host = nullptr;         // pinned block the partitioner's small results come back through
   uint8_t* part_host_dev = nullptr;     // the same block as the device addresses it
   size_t part_host_used = 0;

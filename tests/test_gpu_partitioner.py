@@ -48,6 +48,41 @@ def test_lubm1(engine, lubm1):
     assert_same_as_oracle(engine_artifacts(engine), lubm1["oracle"])
 
 
+def test_both_forms_of_the_tokeniser(lubm1, monkeypatch):
+    """The tokeniser that finds the record starts itself (one pass over the text) and the two-pass form (line scan
+    first) give the oracle's result; an input with more records in a tile than the one-pass form has slots falls back
+    by itself, stays with the two-pass form for its next calls and returns to the one-pass form afterwards."""
+    from opus_amd.engine import Engine
+    from oracle import dap_oracle
+    from parity_util import assert_same_as_oracle, engine_artifacts
+    e = Engine(0)
+    try:
+        def form(st):
+            return "two-pass" if st.ms_stage[0] > 0 else "one-pass"
+        st = e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+        assert form(st) == "one-pass"
+        assert_same_as_oracle(engine_artifacts(e), lubm1["oracle"])
+        monkeypatch.setenv("DX_TWO_PASS", "1")
+        st = e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+        assert form(st) == "two-pass" and st.n_triples == lubm1["n_triples"]
+        assert_same_as_oracle(engine_artifacts(e), lubm1["oracle"])
+        monkeypatch.delenv("DX_TWO_PASS")
+        # 600 records of 13 bytes in the first tile, then ordinary lines
+        text = "".join("<s%03d> <p> <o> .\n" % (i % 700) for i in range(3000)) + lubm1["text"]
+        ref = dap_oracle.run_dap(text, lubm1["class_index"], 4)
+        st = e.partition_text(text.encode(), lubm1["class_index"], 4)
+        assert form(st) == "two-pass" and st.n_triples == ref["n_triples"]
+        assert_same_as_oracle(engine_artifacts(e), ref)
+        for _ in range(8):
+            st = e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+            assert form(st) == "two-pass"
+        st = e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+        assert form(st) == "one-pass"
+        assert_same_as_oracle(engine_artifacts(e), lubm1["oracle"])
+    finally:
+        e.close()
+
+
 EDGE_CASES = {
     "duplicates_and_comments": (
         "# a comment line\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <A> .\n<a> <p> <b> .\n<a> <p> <b> .\n"
