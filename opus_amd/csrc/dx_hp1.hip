@@ -554,10 +554,26 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
     // LDS serves without bank conflicts; the 16-bit masks go through LDS to the thread that owns the chunk's segment.
     uint16_t* cmask = reinterpret_cast<uint16_t*>(fold_lds);  // 2048 masks = 4 KiB, gone before the folding tables are used
     const uint32_t tile_bytes = avail < (uint64_t)LS_TILE ? (uint32_t)avail : (uint32_t)LS_TILE;
+    // A chunk can hold a start (or an empty line) only if it, or the byte before it, holds a byte in [0x0A, 0x0D]: one
+    // chunk in ten on ordinary lines. A cheap test picks those, and only they get the exact treatment (a lane has
+    // eight chunks; the lanes of a wave loop as often as the lane with the most such chunks, three times or so).
+    uint32_t need = 0;
 #pragma unroll
     for (int q = 0; q < LS_TILE / 16 / TK_THREADS; ++q) {
       const uint32_t c = q * TK_THREADS + threadIdx.x;
       const uint32_t off = TK_PRE + c * 16;  // window offset of the chunk
+      const uint4 v = *reinterpret_cast<const uint4*>(&win[off >> 2]);
+      const uint32_t before = win[(off >> 2) - 1];
+      const uint32_t cand = eol_candidates(v.x) | eol_candidates(v.y) | eol_candidates(v.z) | eol_candidates(v.w) |
+                            (eol_candidates(before) & 0x80000000u);
+      if (cand) need |= 1u << q;
+      cmask[c] = 0;
+    }
+    while (need) {
+      const uint32_t q = (uint32_t)__ffs((int)need) - 1;
+      need &= need - 1;
+      const uint32_t c = q * TK_THREADS + threadIdx.x;
+      const uint32_t off = TK_PRE + c * 16;
       const uint4 v = *reinterpret_cast<const uint4*>(&win[off >> 2]);
       const uint32_t before = win[(off >> 2) - 1];
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
