@@ -1354,15 +1354,19 @@ k_node_index(const K* __restrict__ keys, const uint8_t* __restrict__ node_flag, 
 //  - the classes of type rows are few and repeat millions of times: a type row (s, C) lies in every
 //    partition of the class index entry of C, so marking C as used (a plain byte store) is enough, and the
 //    entries (C, 'o', rdf:type) of the partitions of C are written afterwards.
-// Pass 1 writes the per-row decisions es/eo, pass 2 (after the scans) writes the entries.
+// Pass 1 writes the per-row decisions es/eo and counts them per block of 1024 rows, pass 2 (after the scan of those
+// counts) writes the entries.
 __global__ void __launch_bounds__(256)
 k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
             const uint32_t* __restrict__ part_base, int nparts, uint32_t type_pidx, const uint8_t* __restrict__ flags,
-            uint8_t* __restrict__ es_out, uint8_t* __restrict__ eo_out, uint8_t* __restrict__ class_used) {
+            uint8_t* __restrict__ es_out, uint8_t* __restrict__ eo_out, uint8_t* __restrict__ class_used,
+            uint32_t* __restrict__ block_s /*[block]: 's' entries of the block's 1024 rows*/, uint32_t* __restrict__ block_o) {
   // four consecutive rows per lane: 16- and 32-byte loads, one 4-byte store per output instead of four 1-byte ones
+  __shared__ uint32_t lds[8];
   const uint32_t total = part_base[nparts];
   const uint32_t i0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-  if (i0 >= total) return;
+  uint32_t es4 = 0, eo4 = 0;
+  if (i0 < total) {
   uint32_t s[4], o[4], p[4];
   const bool whole = i0 + 4 <= total;
   if (whole) {
@@ -1387,7 +1391,6 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
     const uint32_t first = 4 * blockIdx.x * blockDim.x;
     while (q + 1 < nparts && first >= part_base[q + 1]) ++q;
   }
-  uint32_t es4 = 0, eo4 = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t i = i0 + k;
@@ -1416,24 +1419,79 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
       eo_out[i0 + k] = (uint8_t)(eo4 >> (8 * k));
     }
   }
+  }
+  // the flags are bytes holding 0 or 1: a multiply adds the four of a word up in its top byte
+  uint32_t ts, to;
+  (void)block_excl_scan_256<uint32_t>((es4 * 0x01010101u) >> 24, lds, ts);
+  (void)block_excl_scan_256<uint32_t>((eo4 * 0x01010101u) >> 24, lds, to);
+  if (threadIdx.x == 0) { block_s[blockIdx.x] = ts; block_o[blockIdx.x] = to; }
 }
 
+// Pass 2: the entries' places follow from the scanned block counts and a scan inside the block (same 1024 rows per
+// block, four per lane, as pass 1). The block's entries are put together in LDS and leave it in order, neighbouring
+// lanes writing neighbouring entries.
 template <typename K>  // K: the object entries' word, 32 bits when partition | term | role | predicate fit
 __global__ void __launch_bounds__(256)
 k_vpi_write(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
             const uint32_t* __restrict__ part_base, int nparts, int bits_term, int bits_pred, const uint8_t* __restrict__ es,
-            const uint8_t* __restrict__ eo, const uint32_t* __restrict__ pos_s, const uint32_t* __restrict__ pos_o,
+            const uint8_t* __restrict__ eo, const uint32_t* __restrict__ block_s /*scanned*/, const uint32_t* __restrict__ block_o,
             uint64_t* __restrict__ out_s, K* __restrict__ out_o) {
+  __shared__ uint32_t lds[8];
+  __shared__ uint64_t stage_s[1024];
+  __shared__ K stage_o[1024];
   const uint32_t total = part_base[nparts];
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const bool a = es[i], b = eo[i];
-  if (!a && !b) return;
-  const int q = partition_of_row(part_base, nparts, i);
-  const uint64_t qq = (uint64_t)q << (bits_term + 1 + bits_pred);
-  const uint32_t p = row_p[i];
-  if (a) out_s[pos_s[i]] = qq | ((uint64_t)row_s[i] << (1 + bits_pred)) | p;
-  if (b) out_o[pos_o[i]] = (K)(qq | ((uint64_t)row_o[i] << (1 + bits_pred)) | (1ull << bits_pred) | p);
+  const uint32_t i0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  uint32_t es4 = 0, eo4 = 0;
+  const bool whole = i0 + 4 <= total;
+  if (whole) {
+    es4 = *reinterpret_cast<const uint32_t*>(es + i0);
+    eo4 = *reinterpret_cast<const uint32_t*>(eo + i0);
+  } else {
+    for (int k = 0; k < 4 && i0 + k < total; ++k) {
+      es4 |= (uint32_t)es[i0 + k] << (8 * k);
+      eo4 |= (uint32_t)eo[i0 + k] << (8 * k);
+    }
+  }
+  uint32_t ts, to;
+  uint32_t ps = block_excl_scan_256<uint32_t>((es4 * 0x01010101u) >> 24, lds, ts);
+  uint32_t po = block_excl_scan_256<uint32_t>((eo4 * 0x01010101u) >> 24, lds, to);
+  if (es4 | eo4) {
+    uint32_t s[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, p[4];
+    if (whole) {
+      if (es4) {
+        const longlong2 s01 = *reinterpret_cast<const longlong2*>(row_s + i0), s23 = *reinterpret_cast<const longlong2*>(row_s + i0 + 2);
+        s[0] = (uint32_t)s01.x; s[1] = (uint32_t)s01.y; s[2] = (uint32_t)s23.x; s[3] = (uint32_t)s23.y;
+      }
+      if (eo4) {
+        const longlong2 o01 = *reinterpret_cast<const longlong2*>(row_o + i0), o23 = *reinterpret_cast<const longlong2*>(row_o + i0 + 2);
+        o[0] = (uint32_t)o01.x; o[1] = (uint32_t)o01.y; o[2] = (uint32_t)o23.x; o[3] = (uint32_t)o23.y;
+      }
+      const uint4 pv = *reinterpret_cast<const uint4*>(row_p + i0);
+      p[0] = pv.x; p[1] = pv.y; p[2] = pv.z; p[3] = pv.w;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        const bool in = i0 + k < total;
+        s[k] = in ? (uint32_t)row_s[i0 + k] : 0;
+        o[k] = in ? (uint32_t)row_o[i0 + k] : 0;
+        p[k] = in ? row_p[i0 + k] : 0;
+      }
+    }
+    int q = partition_of_row(part_base, nparts, i0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool a = (es4 >> (8 * k)) & 1, b = (eo4 >> (8 * k)) & 1;
+      if (!a && !b) continue;
+      const uint32_t i = i0 + k;
+      while (q + 1 < nparts && i >= part_base[q + 1]) ++q;
+      const uint64_t qq = (uint64_t)q << (bits_term + 1 + bits_pred);
+      if (a) stage_s[ps++] = qq | ((uint64_t)s[k] << (1 + bits_pred)) | p[k];
+      if (b) stage_o[po++] = (K)(qq | ((uint64_t)o[k] << (1 + bits_pred)) | (1ull << bits_pred) | p[k]);
+    }
+  }
+  __syncthreads();
+  const uint32_t bs = block_s[blockIdx.x], bo = block_o[blockIdx.x];
+  for (uint32_t j = threadIdx.x; j < ts; j += 256) out_s[bs + j] = stage_s[j];
+  for (uint32_t j = threadIdx.x; j < to; j += 256) out_o[bo + j] = stage_o[j];
 }
 
 // counts (out == nullptr) or appends the (class, 'o', rdf:type) entries of the classes in use
@@ -1455,13 +1513,25 @@ k_vpi_type_entries(const uint8_t* __restrict__ class_used, const uint64_t* __res
   }
 }
 
-// base[q] = pos[part_base[q]] for q < nparts (an empty partition takes the next one's), base[nparts] = total
-__global__ void k_vpi_s_bases(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ part_base, int nparts, uint32_t n_rows,
-                              const uint32_t* __restrict__ total, uint32_t* __restrict__ base) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q > nparts) return;
+// base[q] = place of the first 's' entry at or after row part_base[q] for q < nparts (an empty partition takes the next
+// one's), base[nparts] = total
+__global__ void k_vpi_s_bases(const uint32_t* __restrict__ block_s /*scanned*/, const uint8_t* __restrict__ es,
+                              const uint32_t* __restrict__ part_base, int nparts, uint32_t n_rows, const uint32_t* __restrict__ total,
+                              uint32_t* __restrict__ base) {
+  // one block of 256 threads per partition: the flags between the start of the row's block of 1024 and the row, four per thread
+  __shared__ uint32_t lds[8];
+  const int q = blockIdx.x;
   const uint32_t r = part_base[q];
-  base[q] = (q == nparts || r >= n_rows) ? *total : pos[r];
+  if (q == nparts || r >= n_rows) {  // block-uniform
+    if (threadIdx.x == 0) base[q] = *total;
+    return;
+  }
+  const uint32_t first = r & ~1023u;
+  uint32_t mine = 0;
+  for (uint32_t i = first + 4 * threadIdx.x; i < first + 4 * threadIdx.x + 4 && i < r; ++i) mine += es[i];
+  uint32_t sum;
+  (void)block_excl_scan_256<uint32_t>(mine, lds, sum);
+  if (threadIdx.x == 0) base[q] = block_s[r / 1024] + sum;
 }
 
 template <typename K>
@@ -2577,20 +2647,21 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   std::vector<uint32_t> hvb(nparts + 1, 0);
   if (n_rows) {
     DevBuf<uint8_t> es(pool, n_rows), eo(pool, n_rows);
-    DevBuf<uint32_t> pos_s(pool, n_rows), pos_o(pool, n_rows);
+    const unsigned vpi_blocks = blocks(((uint64_t)n_rows + 3) / 4);  // 1024 rows each
+    DevBuf<uint32_t> block_s(pool, vpi_blocks + 1), block_o(pool, vpi_blocks + 1);
     DevBuf<uint8_t> class_used(pool, n_terms);
     DevBuf<unsigned long long> n_type_ent(pool, 2);
     DevBuf<uint32_t> totals(pool, 2);
     DX_HIP(hipMemsetAsync(class_used.p, 0, class_used.bytes(), s));
     DX_HIP(hipMemsetAsync(n_type_ent.p, 0, 16, s));
-    hipLaunchKernelGGL(k_vpi_flags, dim3(blocks(((uint64_t)n_rows + 3) / 4)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
-                       ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p);
-    exclusive_scan_u8_u32(pool, es.p, pos_s.p, n_rows, totals.p, s);
-    exclusive_scan_u8_u32(pool, eo.p, pos_o.p, n_rows, totals.p + 1, s);
+    hipLaunchKernelGGL(k_vpi_flags, dim3(vpi_blocks), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
+                       ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p, block_s.p, block_o.p);
+    exclusive_scan_u32_u32(pool, block_s.p, block_s.p, vpi_blocks, totals.p, s);
+    exclusive_scan_u32_u32(pool, block_o.p, block_o.p, vpi_blocks, totals.p + 1, s);
     hipLaunchKernelGGL(k_vpi_type_entries<uint64_t>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, owned, n_terms, ps.type_pidx,
                        bits_term, bits_pred, n_type_ent.p, (uint64_t*)nullptr);
     DevBuf<uint32_t> sb(pool, nparts + 1);
-    hipLaunchKernelGGL(k_vpi_s_bases, dim3(1), dim3(128), 0, s, pos_s.p, d_part_base.p, nparts, n_rows, totals.p, sb.p);
+    hipLaunchKernelGGL(k_vpi_s_bases, dim3(nparts + 1), dim3(256), 0, s, block_s.p, es.p, d_part_base.p, nparts, n_rows, totals.p, sb.p);
     uint32_t h_tot[2] = {0, 0};
     unsigned long long h_type_ent = 0;
     std::vector<uint32_t> hsb(nparts + 1);
@@ -2608,12 +2679,12 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     auto object_entries = [&](auto zero) {
       using K = decltype(zero);
       DevBuf<K> ent(pool, n_o_raw);
-      hipLaunchKernelGGL(k_vpi_write<K>, dim3(blocks(n_rows)), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts, bits_term,
-                         bits_pred, es.p, eo.p, pos_s.p, pos_o.p, ps.vpi_s.p, ent.p);
+      hipLaunchKernelGGL(k_vpi_write<K>, dim3(vpi_blocks), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts, bits_term,
+                         bits_pred, es.p, eo.p, block_s.p, block_o.p, ps.vpi_s.p, ent.p);
       if (h_type_ent)
         hipLaunchKernelGGL(k_vpi_type_entries<K>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, owned, n_terms, ps.type_pidx,
                            bits_term, bits_pred, n_type_ent.p + 1, ent.p + h_tot[1]);
-      es.reset(); eo.reset(); pos_s.reset(); pos_o.reset();
+      es.reset(); eo.reset(); block_s.reset(); block_o.reset();
       if constexpr (sizeof(K) == 4) radix_sort_u32(pool, ent, n_o_raw, ent_bits, s);
       else radix_sort_u64(pool, ent, n_o_raw, ent_bits, s);
       DevBuf<uint8_t> fl(pool, n_o_raw);

@@ -250,7 +250,7 @@ void exclusive_scan_u32_u64(DevPool& pool, const uint32_t* in, uint64_t* out, si
 }
 
 // ---- radix sort ----------------------------------------------------------------------------------
-// Digits of 8 bits, least significant first. Per pass: (1) per-tile digit histogram in LDS, (2) scan of the [digit][tile] matrix, (3) scatter. A tile is
+// Digits of 8 (or 9, see radix_sort_impl) bits, least significant first. Per pass: (1) per-tile digit histogram in LDS, (2) scan of the [digit][tile] matrix, (3) scatter. A tile is
 // 4096 keys; each of the 4 waves of a block owns a contiguous 1024-key quarter, so (wave, round, lane) order equals
 // key order and ranking by wave-level ballots keeps the sort stable. (Sixteen keys per lane: eight per lane means
 // twice the tiles to scan and runs half as long in the scatter, thirty-two too many registers.)
@@ -456,33 +456,54 @@ k_rs_scatter(const K* __restrict__ kin, const uint32_t* __restrict__ vin, K* __r
   }
 }
 
-// The passes alternate between the caller's array and a scratch array of the same size. When `keys_buf` is
-// given (it must be the pool allocation `keys` points at, with n elements) and the result ends in the scratch
-// array, the two allocations change places instead of being copied (an odd number of passes over 13 M keys
-// would otherwise end with a 100 MB copy).
 template <typename K, int BITS>
-static void radix_sort_passes(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
-  constexpr int R = 1 << BITS;
+static void radix_sort_pass(DevPool& pool, const K* kin, const uint32_t* vin /*null: keys only*/, K* kout, uint32_t* vout, size_t n, int shift,
+                            uint32_t* hist, size_t stride, unsigned ntiles, hipStream_t s) {
+  hipLaunchKernelGGL((k_rs_hist<K, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, hist, stride, ntiles);
+  exclusive_scan_u32_u32(pool, hist, hist, (size_t)(1 << BITS) * stride, nullptr, s);
+  if (vin)
+    hipLaunchKernelGGL((k_rs_scatter<K, true, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist, stride, ntiles);
+  else
+    hipLaunchKernelGGL((k_rs_scatter<K, false, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist, stride, ntiles);
+}
+
+// Digits are 8 bits wide, except that the topmost passes take 9 where that saves a pass: 49-bit keys (five predicate
+// bits over two 22-bit terms, LUBM-100) sort in five 8-bit passes and one 9-bit pass instead of seven passes. A 9-bit
+// pass costs about 1.4 passes of 8 bits (half as long runs in the scatter, a ninth ballot per ranking step), so all
+// digits at 9 bits lose (0.67 ms against 0.62 ms for 13 M keys) and one in place of two wins.
+template <typename K>
+static void radix_sort_impl(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
+  if (n < 2 || key_bits <= 0) return;
+  if (n >= (1ull << 32)) throw DxError(DX_E_RANGE, "radix_sort_u64: more than 2^32 keys");
+  int passes = (key_bits + 7) / 8, wide = 0;
+  if ((key_bits + 8) / 9 < passes && key_bits - 8 * ((key_bits + 8) / 9) <= 2) {  // one pass saved for at most two wide ones
+    passes = (key_bits + 8) / 9;
+    wide = key_bits - 8 * passes;  // that many passes take 9 bits
+  }
   const unsigned ntiles = (unsigned)((n + RS_TILE - 1) / RS_TILE);
   DevBuf<K> ktmp(pool, keys_buf ? keys_buf->n : n);
   DevBuf<uint32_t> vtmp(pool, vals ? n : 1);
   const size_t stride = ((size_t)ntiles + 15) & ~(size_t)15;  // rows of the count matrix begin on 64-byte boundaries
-  DevBuf<uint32_t> hist(pool, (size_t)R * stride);
-  const int passes = (key_bits + BITS - 1) / BITS;
+  DevBuf<uint32_t> hist(pool, (size_t)(wide ? 512 : 256) * stride);
   K* kin = keys; K* kout = ktmp.p;
   uint32_t* vin = vals; uint32_t* vout = vtmp.p;
+  int shift = 0;
   for (int p = 0; p < passes; ++p) {
-    const int shift = p * BITS;
-    hipLaunchKernelGGL((k_rs_hist<K, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, shift, hist.p, stride, ntiles);
-    exclusive_scan_u32_u32(pool, hist.p, hist.p, (size_t)R * stride, nullptr, s);
-    if (vals)
-      hipLaunchKernelGGL((k_rs_scatter<K, true, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, stride, ntiles);
-    else
-      hipLaunchKernelGGL((k_rs_scatter<K, false, BITS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift, hist.p, stride, ntiles);
+    if (p >= passes - wide) {
+      radix_sort_pass<K, 9>(pool, kin, vals ? vin : nullptr, kout, vout, n, shift, hist.p, stride, ntiles, s);
+      shift += 9;
+    } else {
+      radix_sort_pass<K, 8>(pool, kin, vals ? vin : nullptr, kout, vout, n, shift, hist.p, stride, ntiles, s);
+      shift += 8;
+    }
     std::swap(kin, kout);
     std::swap(vin, vout);
   }
   DX_HIP(hipGetLastError());
+  // The passes alternate between the caller's array and a scratch array of the same size. When `keys_buf` is
+  // given (it must be the pool allocation `keys` points at, with n elements) and the result ends in the scratch
+  // array, the two allocations change places instead of being copied (an odd number of passes over 13 M keys
+  // would otherwise end with a 100 MB copy).
   if (kin != keys) {
     if (keys_buf && !vals) {
       std::swap(*keys_buf, ktmp);  // the stream is in order: the old array goes back to the pool only for later launches
@@ -491,17 +512,6 @@ static void radix_sort_passes(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint3
       if (vals) DX_HIP(hipMemcpyAsync(vals, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
   }
-}
-
-template <typename K>
-static void radix_sort_impl(DevPool& pool, K* keys, DevBuf<K>* keys_buf, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
-  if (n < 2 || key_bits <= 0) return;
-  if (n >= (1ull << 32)) throw DxError(DX_E_RANGE, "radix_sort_u64: more than 2^32 keys");
-  // 8-bit digits. (9-bit digits would sort 49-bit keys in six passes instead of seven, but the runs a tile writes per
-  // digit halve and a ninth ballot joins every ranking step: 0.67 ms against 0.62 ms for 13 M keys. One launch that
-  // scans the matrix row by row, the rows exchanging their sums through flagged words, measured 12 us against the
-  // 10 us of the two launches of the plain scan.)
-  radix_sort_passes<K, 8>(pool, keys, keys_buf, vals, n, key_bits, s);
 }
 
 void radix_sort_u64(DevPool& pool, uint64_t* keys, uint32_t* vals, size_t n, int key_bits, hipStream_t s) {
