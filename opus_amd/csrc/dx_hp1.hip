@@ -885,7 +885,7 @@ k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
 // term's first occurrence in the text); the slot now maps hash -> id.
 __global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
 k_entry_assign(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
-               const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot, const uint8_t* __restrict__ first,
+               const ulonglong2* __restrict__ ent, uint32_t* __restrict__ e_slot, const uint8_t* __restrict__ first,
                const uint32_t* __restrict__ firsts_before /*[tile]: representatives in the tiles before it*/, DictSlot* __restrict__ ht,
                uint32_t* __restrict__ term_len, uint64_t* __restrict__ term_src) {
   const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
@@ -903,6 +903,7 @@ k_entry_assign(const uint32_t* __restrict__ tile_first, const uint32_t* __restri
       const uint32_t id = run + (uint32_t)__popcll(b & lt);
       const uint64_t rep = ent[base + i].x;
       ht[e_slot[base + i]].val = id;
+      e_slot[base + i] = id;  // a representative knows its id already: k_entry_to_id leaves it alone
       term_len[id] = (uint32_t)(rep & ((1ull << kRepLenBits) - 1));
       term_src[id] = rep >> kRepLenBits;
     }
@@ -910,15 +911,16 @@ k_entry_assign(const uint32_t* __restrict__ tile_first, const uint32_t* __restri
   }
 }
 
-// entry -> id, in place of the entry's slot
+// entry -> id, in place of the entry's slot (the representatives got theirs from k_entry_assign)
 __global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
 k_entry_to_id(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
-              const DictSlot* __restrict__ ht, uint32_t* __restrict__ e_slot_then_id) {
+              const DictSlot* __restrict__ ht, const uint8_t* __restrict__ first, uint32_t* __restrict__ e_slot_then_id) {
   const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
   const uint64_t base = 3ull * tile_first[tile];
   const uint32_t L = tile_leaders[tile];
-  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) e_slot_then_id[base + i] = (uint32_t)ht[e_slot_then_id[base + i]].val;
+  for (uint32_t i = threadIdx.x & 63; i < L; i += 64)
+    if (!first[base + i]) e_slot_then_id[base + i] = (uint32_t)ht[e_slot_then_id[base + i]].val;
 }
 
 __global__ void __launch_bounds__(256) k_ht_clear(DictSlot* __restrict__ ht, uint64_t cap) {
@@ -1547,6 +1549,51 @@ k_compact_u64(const K* __restrict__ in, const uint8_t* __restrict__ flag, const 
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && flag[i]) out[pos[i]] = in[i];
 }
+// Distinct keys of a sorted array without a flag and a position per key: blocks of 1024 keys count their distinct keys
+// (a key differs from the one before it), the counts are scanned, and the second kernel finds the places inside
+// the block again, puts the block's distinct keys together in LDS and writes them out side by side.
+template <typename K>
+__device__ __forceinline__ uint32_t distinct_flags4(const K* __restrict__ keys, uint32_t n, uint32_t i0, K (&k)[4]) {
+  uint32_t f = 0;
+  if (i0 >= n) return 0;
+  K prev = i0 ? keys[i0 - 1] : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (i0 + j < n) {
+      k[j] = keys[i0 + j];
+      if (i0 + j == 0 || k[j] != prev) f |= 1u << j;
+      prev = k[j];
+    }
+  }
+  return f;
+}
+template <typename K>
+__global__ void __launch_bounds__(256)
+k_distinct_count(const K* __restrict__ keys, uint32_t n, uint32_t* __restrict__ block_cnt) {
+  __shared__ uint32_t lds[8];
+  K k[4];
+  const uint32_t f = distinct_flags4(keys, n, 4 * (blockIdx.x * blockDim.x + threadIdx.x), k);
+  uint32_t total;
+  (void)block_excl_scan_256<uint32_t>(__popc(f), lds, total);
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = total;
+}
+template <typename K>
+__global__ void __launch_bounds__(256)
+k_distinct_compact(const K* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ block_base /*scanned counts*/, uint64_t* __restrict__ out) {
+  __shared__ uint32_t lds[8];
+  __shared__ K stage[1024];
+  K k[4];
+  const uint32_t f = distinct_flags4(keys, n, 4 * (blockIdx.x * blockDim.x + threadIdx.x), k);
+  uint32_t total;
+  uint32_t at = block_excl_scan_256<uint32_t>(__popc(f), lds, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (f & (1u << j)) stage[at++] = k[j];
+  __syncthreads();
+  const uint32_t base = block_base[blockIdx.x];
+  for (uint32_t j = threadIdx.x; j < total; j += 256) out[base + j] = (uint64_t)stage[j];
+}
+
 // base[q] = first index whose partition field is >= q (keys sorted)
 __global__ void k_vpi_bases(const uint64_t* __restrict__ keys, uint32_t n, int shift, int nparts, uint32_t* __restrict__ base) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2329,7 +2376,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   if (n_occ) {
     hipLaunchKernelGGL(k_entry_assign, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, ent.p,
                        e_slot.p, first.p, tile_firsts.p, ht.p, term_len.p, term_src.p);
-    hipLaunchKernelGGL(k_entry_to_id, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, ht.p, e_slot.p);
+    hipLaunchKernelGGL(k_entry_to_id, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, ht.p, first.p, e_slot.p);
     if (fused)
       hipLaunchKernelGGL(k_encode_tiles, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, tile_counts.p, ntiles, t_entry.p, n_slots, e_slot.p,
                          kind_slots.p, S.p, P.p, O.p, kind.p, fact.p + nt_pad, fact.p + 2 * nt_pad, fact.p + 3 * nt_pad, is_pred);
@@ -2687,14 +2734,14 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
       es.reset(); eo.reset(); block_s.reset(); block_o.reset();
       if constexpr (sizeof(K) == 4) radix_sort_u32(pool, ent, n_o_raw, ent_bits, s);
       else radix_sort_u64(pool, ent, n_o_raw, ent_bits, s);
-      DevBuf<uint8_t> fl(pool, n_o_raw);
-      DevBuf<uint32_t> fp(pool, n_o_raw);
-      if (n_o_raw) hipLaunchKernelGGL(k_flag_distinct<K>, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, n_o_raw, fl.p);
-      exclusive_scan_u8_u32(pool, fl.p, fp.p, n_o_raw, d_total.p, s);
+      const unsigned dblocks = blocks(((uint64_t)n_o_raw + 3) / 4);  // 1024 entries each
+      DevBuf<uint32_t> dcnt(pool, (size_t)dblocks + 1);
+      if (n_o_raw) hipLaunchKernelGGL(k_distinct_count<K>, dim3(dblocks), dim3(256), 0, s, ent.p, n_o_raw, dcnt.p);
+      exclusive_scan_u32_u32(pool, dcnt.p, dcnt.p, n_o_raw ? dblocks : 0, d_total.p, s);
       fetch.add(&n_o, d_total.p, 4);
       fetch.sync();
       ps.vpi_o = DevBuf<uint64_t>(pool, n_o);
-      if (n_o_raw) hipLaunchKernelGGL(k_compact_u64<K>, dim3(blocks(n_o_raw)), dim3(256), 0, s, ent.p, fl.p, fp.p, n_o_raw, ps.vpi_o.p);
+      if (n_o_raw) hipLaunchKernelGGL(k_distinct_compact<K>, dim3(dblocks), dim3(256), 0, s, ent.p, n_o_raw, dcnt.p, ps.vpi_o.p);
     };
     if (ent_bits <= 32) object_entries((uint32_t)0); else object_entries((uint64_t)0);
     DevBuf<uint32_t> vb(pool, nparts + 1);
