@@ -861,24 +861,43 @@ k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
               const uint8_t* __restrict__ text, const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot,
               const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ tile_firsts,
               uint32_t* __restrict__ collision) {
+  // A third of a tile's entries are undecided. The wave first lists them (their numbers inside the tile, in LDS), then
+  // works through the list with all lanes busy: one chain of dependent loads per 64 undecided entries instead of one
+  // per 64 entries of any kind.
+  constexpr uint32_t kList = 512;
+  __shared__ uint16_t list[EN_TILES_PER_BLOCK][kList];
   const unsigned tile = blockIdx.x * EN_TILES_PER_BLOCK + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint64_t base = 3ull * tile_first[tile];
   const uint32_t L = tile_leaders[tile];
   uint32_t mine_cnt = 0;
-  for (uint32_t i = threadIdx.x & 63; i < L; i += 64) {
-    if (first[base + i] != kMaybeFirst) continue;
-    const uint64_t mine = ent[base + i].x, r = ht[e_slot[base + i]].val;
-    const uint8_t f = mine == r;
-    if (!f) {
-      const uint64_t lm = mine & ((1ull << kRepLenBits) - 1);
-      if (lm != (r & ((1ull << kRepLenBits) - 1)) || diff_global_wide(text + (mine >> kRepLenBits), text + (r >> kRepLenBits), (uint32_t)lm)) *collision = 1;
+  for (uint32_t i0 = 0; i0 < L;) {  // wave-uniform
+    uint32_t m = 0;                  // entries listed
+    for (; i0 < L && m + 64 <= kList; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool maybe = i < L && first[base + i] == kMaybeFirst;
+      const uint64_t b = __ballot(maybe);
+      if (maybe) list[w][m + (uint32_t)__popcll(b & lt)] = (uint16_t)i;  // a 32 KiB tile has fewer than 2^16 entries
+      m += (uint32_t)__popcll(b);
     }
-    first[base + i] = f;
-    mine_cnt += f;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < m; j += 64) {
+      const uint32_t i = list[w][j];
+      const uint64_t mine = ent[base + i].x, r = ht[e_slot[base + i]].val;
+      const uint8_t f = mine == r;
+      if (!f) {
+        const uint64_t lm = mine & ((1ull << kRepLenBits) - 1);
+        if (lm != (r & ((1ull << kRepLenBits) - 1)) || diff_global_wide(text + (mine >> kRepLenBits), text + (r >> kRepLenBits), (uint32_t)lm)) *collision = 1;
+      }
+      first[base + i] = f;
+      mine_cnt += f;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   mine_cnt = wave_reduce_u32(mine_cnt);
-  if ((threadIdx.x & 63) == 0) tile_firsts[tile] = mine_cnt;
+  if (lane == 0) tile_firsts[tile] = mine_cnt;
 }
 
 // The representatives get their ids (their rank among the representatives, i.e. ids grow with the place of a
