@@ -1244,7 +1244,7 @@ const char* dx_result_virtual_term(dx_result* r, int64_t id) {
   return r->virtual_terms[(size_t)(-id - 2)].c_str();
 }
 
-const char* dx_result_plan(dx_result* r) { return r ? r->plan.c_str() : ""; }
+const char* dx_result_plan(dx_result* r) { return r ? r->plan_text().c_str() : ""; }
 
 void dx_result_free(dx_result* r) { delete r; }
 

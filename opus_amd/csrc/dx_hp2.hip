@@ -555,7 +555,8 @@ int find_root(std::vector<int>& uf, int x) { while (uf[x] != x) x = uf[x] = uf[u
 // may_allocate == false (the entry point that allocates nothing): whatever the plan needs beyond the tables
 // themselves -- their distinct counts, the duplicate-free copy of a table read by UNION arms -- has to exist
 // already, because gathering it takes device memory from the allocator.
-Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true) {
+// text_hash != 0: the join order found for this statement text over tables with these statistics is remembered.
+Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true, uint64_t text_hash = 0) {
   Plan plan;
   const long long kLookup = (-0x7FFFFFFFFFFFFFFFll - 1);
   auto add_const = [&](const std::string& s, bool is_virtual) -> int {
@@ -693,6 +694,27 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true) {
     std::vector<int> best_order, cur;
     std::vector<double> best_rows, cur_rows;
     double best_cost = 1e300;
+    // everything the search below looks at, folded into the key of the remembered order
+    uint64_t order_key = 0;
+    if (text_hash && n > 2) {
+      uint64_t h = text_hash ^ 0x9E3779B97F4A7C15ull * (uint64_t)plan.n_classes;
+      auto fold = [&](uint64_t v) { h = mix64(h ^ v); };
+      auto fold_d = [&](double d) { uint64_t v; memcpy(&v, &d, 8); fold(v); };
+      for (const PlanRel& r : rels) {
+        fold((uint64_t)r.ncols);
+        for (int c = 0; c < r.ncols; ++c) { fold((uint64_t)r.cls[c]); fold_d(r.dist[c]); }
+        fold_d(r.est);
+        fold_d(r.rows_plan);
+      }
+      order_key = h ? h : 1;
+      auto it = ctx->q_orders.find(order_key);
+      if (it != ctx->q_orders.end() && (int)it->second.order.size() == n) {
+        for (int i : it->second.order) plan.rels.push_back(rels[i]);
+        plan.est_rows = it->second.rows;
+        if ((int)plan.rels.size() > MAXSTEPS) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 30 sub-selects");
+        return plan;
+      }
+    }
     std::vector<bool> used(n, false);
     long budget = 200000;  // nodes of the search tree; beyond it the best order found so far is used
     struct State { double rows; std::vector<double> d; };
@@ -740,6 +762,10 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true) {
     for (int i : best_order) plan.rels.push_back(rels[i]);
     plan.est_rows = best_rows;
     if ((int)plan.rels.size() != n) throw DxError(DX_E_INVAL, "planner found no join order");
+    if (order_key) {
+      if (ctx->q_orders.size() > 4096) ctx->q_orders.clear();
+      ctx->q_orders[order_key] = dx_ctx::JoinOrder{best_order, best_rows};
+    }
   }
   if ((int)plan.rels.size() > MAXSTEPS) throw DxError(DX_E_UNSUPPORTED, "SQL: more than 30 sub-selects");
   return plan;
@@ -846,12 +872,28 @@ void query_context_setup(dx_ctx* ctx) {
   if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }
 }
 
+static bool plan_cache_enabled() {
+  const char* e = getenv("DX_NO_PLAN_CACHE");
+  return !(e && *e == '1');
+}
+// the parsed form of a statement text, parsed once per context
+static std::shared_ptr<const SqlQuery> parsed_statement(dx_ctx* ctx, const std::string& sql) {
+  if (!plan_cache_enabled()) return std::make_shared<const SqlQuery>(parse_sql(sql));
+  auto it = ctx->q_parsed.find(sql);
+  if (it != ctx->q_parsed.end()) return it->second;
+  auto p = std::make_shared<const SqlQuery>(parse_sql(sql));
+  if (ctx->q_parsed.size() > 4096) ctx->q_parsed.clear();
+  ctx->q_parsed.emplace(sql, p);
+  return p;
+}
+
 // `pool` supplies every device buffer of the statement's execution: the context's caching allocator, or a
 // fixed arena (then may_allocate is false and nothing else may be allocated either).
 static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, DevPool& pool, bool may_allocate) {
   const auto t_host0 = std::chrono::steady_clock::now();
-  const SqlQuery q = parse_sql(sql);
-  Plan plan = make_plan(ctx, q, may_allocate);
+  const std::shared_ptr<const SqlQuery> parsed = parsed_statement(ctx, sql);
+  const SqlQuery& q = *parsed;
+  Plan plan = make_plan(ctx, q, may_allocate, plan_cache_enabled() ? (uint64_t)std::hash<std::string>{}(sql) | 1 : 0);
   const double plan_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();
   if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
   for (auto& r : plan.rels)
@@ -1096,16 +1138,6 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         DX_HIP(hipEventRecord(ev1, s));
         wait_published(ctx, hb, seq);
       }
-      std::ostringstream explain;
-      explain << "parse+plan " << (long)plan_us << " us\n";
-      for (int k = 0; k < nsteps; ++k) {
-        const PlanRel& r = plan.rels[k];
-        explain << (k ? "join " : "scan ");
-        for (size_t a = 0; a < r.arms.size(); ++a)
-          explain << (a ? " UNION " : "") << r.arms[a].t->view << "[" << r.arms[a].t->rows << " rows"
-                  << (r.arms[a].fs >= 0 ? ", s filter" : "") << (r.arms[a].fo >= 0 ? ", o filter" : "") << "]";
-        explain << " -> " << hb->counters[k] << " rows\n";
-      }
       if (fused && hb->counters[MAXSTEPS + 1]) {  // some step's intermediate did not fit its table in LDS
         regular_steps |= hb->counters[MAXSTEPS + 1];
         if (ctx->q_regular_steps.size() > 4096) ctx->q_regular_steps.clear();
@@ -1141,7 +1173,13 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         }
         DX_HIP(hipStreamSynchronize(s));
       }
-      res->plan = explain.str();
+      res->plan_us = plan_us;  // the text of the plan is put together when it is asked for
+      res->plan_steps.resize(nsteps);
+      for (int k = 0; k < nsteps; ++k) {
+        const PlanRel& r = plan.rels[k];
+        for (const auto& a : r.arms) res->plan_steps[k].arms.push_back({a.t->view, a.t->rows, a.fs >= 0, a.fo >= 0});
+        res->plan_steps[k].rows_out = hb->counters[k];
+      }
       return res;
     }
     throw DxError(DX_E_RANGE, "query did not converge on buffer sizes");

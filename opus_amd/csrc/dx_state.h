@@ -115,7 +115,7 @@ struct CatalogTable {
 
 }  // namespace dx
 
-namespace dx { struct RcclComm; }
+namespace dx { struct RcclComm; struct SqlQuery; }
 
 struct dx_ctx {
   int device = 0;
@@ -140,6 +140,11 @@ struct dx_ctx {
   hipEvent_t file_stage_ev[2] = {nullptr, nullptr};
   void* q_counters = nullptr;           // device: a statement's row counters and its last-block ticket, zero between statements
   std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
+  // Statements come again: the parsed form is kept per text, and the join order the search found per (text, numbers the
+  // search looked at), so a repeated statement over tables with the same statistics skips both (DX_NO_PLAN_CACHE=1: never).
+  std::unordered_map<std::string, std::shared_ptr<const dx::SqlQuery>> q_parsed;
+  struct JoinOrder { std::vector<int> order; std::vector<double> rows; };
+  std::unordered_map<uint64_t, JoinOrder> q_orders;
   bool q_counters_dirty = false;        // a statement failed between its first and its last kernel: clear before the next
   std::vector<hipEvent_t> part_events;  // the partitioner's stage timers, created once
   int part_two_pass_calls = 0;          // calls that still skip the fused tokeniser: an input had a tile with more records than it has slots
@@ -271,7 +276,30 @@ struct dx_result {
   std::vector<std::string> names;
   std::vector<dx::DevBuf<int64_t>> cols;   // one per selected column (bindings mode)
   std::vector<std::string> virtual_terms;  // projected constants: id -(2 + index)
-  std::string plan;                        // join order with the row count after every step
+  // Join order with the row count after every step. A statement leaves the facts (plan_steps) and the text is put
+  // together when it is first asked for: formatting it costs microseconds that a short statement does not have.
+  std::string plan;
+  struct PlanArm { std::string view; uint64_t rows; bool fs, fo; };
+  struct PlanStep { std::vector<PlanArm> arms; uint64_t rows_out; };
+  std::vector<PlanStep> plan_steps;
+  double plan_us = -1;
+  const std::string& plan_text() {
+    if (plan_us >= 0) {
+      std::string t = "parse+plan " + std::to_string((long)plan_us) + " us\n";
+      for (size_t k = 0; k < plan_steps.size(); ++k) {
+        t += k ? "join " : "scan ";
+        for (size_t a = 0; a < plan_steps[k].arms.size(); ++a) {
+          const PlanArm& arm = plan_steps[k].arms[a];
+          t += (a ? " UNION " : "") + arm.view + "[" + std::to_string(arm.rows) + " rows" + (arm.fs ? ", s filter" : "") + (arm.fo ? ", o filter" : "") + "]";
+        }
+        t += " -> " + std::to_string(plan_steps[k].rows_out) + " rows\n";
+      }
+      plan = t + plan;
+      plan_us = -1;
+      plan_steps.clear();
+    }
+    return plan;
+  }
 };
 
 namespace dx {

@@ -57,6 +57,25 @@ def test_lubm_query_counts_and_bindings(loaded, lubm1, name):
     assert rows == ref["rows"], name  # sorted decoded bindings, bit-exact
 
 
+def test_remembered_parse_and_join_order_change_nothing(loaded, lubm1, monkeypatch):
+    """A statement that comes again skips the parser and the join-order search (its text and the statistics the
+    search looked at are the key): same plan, same count as with DX_NO_PLAN_CACHE=1, which always parses and searches."""
+    from opus_amd.engine import DX_QUERY_COUNT
+    e, translated = loaded
+
+    def plan_lines(r):
+        return [ln for ln in r.plan.split("\n") if not ln.startswith("parse+plan")]
+    for name in ("Q2.txt", "Q9.txt", "Q8.txt", "Q4.txt"):
+        first, _ = _run_file(e, translated[name], DX_QUERY_COUNT)      # may or may not be remembered already
+        again, _ = _run_file(e, translated[name], DX_QUERY_COUNT)      # remembered
+        monkeypatch.setenv("DX_NO_PLAN_CACHE", "1")
+        fresh, _ = _run_file(e, translated[name], DX_QUERY_COUNT)
+        monkeypatch.delenv("DX_NO_PLAN_CACHE")
+        assert first.count == again.count == fresh.count, name
+        assert plan_lines(first) == plan_lines(again) == plan_lines(fresh), name
+        assert len(plan_lines(fresh)) >= 3
+
+
 @pytest.fixture(scope="module")
 def loaded_swat(lubm1_swat):
     """The same for the second namespace the reference ships queries for (queries/lubm10240)."""
