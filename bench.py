@@ -479,8 +479,11 @@ def main():
         if os.path.exists(pmc_path) and total_univ == 100 and world == 1 and args.partitions == 8:
             pmc = json.load(open(pmc_path))
             names = [w for w in dom.replace("+", " ").split() if w.startswith("k_")]
-            if names and all(nm in pmc for nm in names):
-                traffic = sum(pmc[nm]["bytes"] for nm in names)
+            # a templated kernel is listed with its arguments (k_tokenise<true>): the instantiation this run used is the
+            # one the profile of the same command holds
+            found = [[k for k in pmc if k == nm or k.startswith(nm + "<")] for nm in names]
+            if names and all(len(f) == 1 for f in found):
+                traffic = sum(pmc[f[0]]["bytes"] for f in found)
         # algorithmic bytes of the whole partitioner: the text once + R * (24 + 16) B per triple (R = replication:
         # 24 B per row of a first-level partition, 16 B per row of a vertical-partition table)
         R = st.n_rows / max(1, st.n_triples)
