@@ -702,7 +702,14 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
         while (b[2] < e[2] && lds_byte(win, b[2]) <= 0x20) ++b[2];
       }
       if (odd) {
-        tokenise_record_slow(text, n, gstart, seed, out);
+        // The slow path is a call: what it fills in lives in memory. A record of its own keeps the fast path's results
+        // in registers (filled in place, they were stored to and loaded from scratch memory for every record: 64 bytes
+        // per lane, more HBM writes than the kernel's real output).
+        RecordOut slow;
+        tokenise_record_slow(text, n, gstart, seed, slow);
+        out.bad = slow.bad;
+        out.kind = slow.kind;
+        for (int k = 0; k < 3; ++k) { out.rep[k] = slow.rep[k]; out.hash[k] = slow.hash[k]; }
       } else {
         {  // object hash, four words per round
           uint32_t q = b[2], i = q >> 2;
