@@ -240,6 +240,9 @@ __device__ __forceinline__ void stmt_epilogue(const Epilogue& ep, unsigned long 
 }
 
 // `pre`: the values of the filtered columns were requested earlier (pre_s / pre_o) and are not loaded again
+// v[i] for an index known only at run time, without making the compiler keep v in scratch memory
+__device__ __forceinline__ int64_t pick3(const int64_t (&v)[3], int i) { return i == 0 ? v[0] : i == 1 ? v[1] : v[2]; }
+
 __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restrict__ consts, int64_t want_s, int64_t want_o, uint32_t i,
                                         int64_t v[3], bool pre = false, int64_t pre_s = 0, int64_t pre_o = 0) {
   if (a.direct) {
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
         if (p.nkey == 0) {
           head[j] = nI ? 0u : kNil;
         } else {
-          const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
+          const int64_t k0 = pick3(v[j], p.key_src[0]), k1 = p.nkey == 2 ? pick3(v[j], p.key_src[1]) : 0;
           const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
           head[j] = kLds ? lds_heads[(uint32_t)h & (kLdsHeads - 1)] : p.heads[(uint32_t)h & p.hmask];
         }
@@ -485,7 +488,7 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
       hit[j] = kNil;
       nhit[j] = 0;
       if (p.nkey == 0) { nhit[j] = head[j] != kNil ? nI : 0u; n += nhit[j]; continue; }
-      const int64_t k0 = v[j][p.key_src[0]], k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
+      const int64_t k0 = pick3(v[j], p.key_src[0]), k1 = p.nkey == 2 ? pick3(v[j], p.key_src[1]) : 0;
       for (uint32_t r = head[j]; r != kNil; r = chain_next(r))
         if (matches(r, k0, k1)) {
           if (!nhit[j]) hit[j] = r;
@@ -499,14 +502,14 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
       if (!nhit[j]) continue;
-      const int64_t k0 = p.nkey ? v[j][p.key_src[0]] : 0, k1 = p.nkey == 2 ? v[j][p.key_src[1]] : 0;
+      const int64_t k0 = p.nkey ? pick3(v[j], p.key_src[0]) : 0, k1 = p.nkey == 2 ? pick3(v[j], p.key_src[1]) : 0;
       // the usual row has one match, remembered from the counting walk; only several matches walk the chain again
       const bool single = p.nkey != 0 && nhit[j] == 1;
       for (uint32_t r = single ? hit[j] : head[j]; r != kNil; r = single ? kNil : (p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : chain_next(r))) {
         if (!single && !matches(r, k0, k1)) continue;
         if (pos < p.out.cap) {
           for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
-          for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = v[j][p.new_src[c]];
+          for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = pick3(v[j], p.new_src[c]);
         }
         ++pos;
       }
