@@ -867,6 +867,7 @@ __global__ void __launch_bounds__(64 * EN_TILES_PER_BLOCK)
 k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_leaders, unsigned ntiles,
               const uint8_t* __restrict__ text, const ulonglong2* __restrict__ ent, const uint32_t* __restrict__ e_slot,
               const DictSlot* __restrict__ ht, uint8_t* __restrict__ first, uint32_t* __restrict__ tile_firsts,
+              uint32_t* __restrict__ tile_bytes /*[tile]: bytes of the tile's representatives, i.e. its share of the string pool*/,
               uint32_t* __restrict__ collision) {
   // A third of a tile's entries are undecided. The wave first lists them (their numbers inside the tile, in LDS), then
   // works through the list with all lanes busy: one chain of dependent loads per 64 undecided entries instead of one
@@ -879,7 +880,7 @@ k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const uint64_t base = 3ull * tile_first[tile];
   const uint32_t L = tile_leaders[tile];
-  uint32_t mine_cnt = 0;
+  uint32_t mine_cnt = 0, mine_bytes = 0;
   for (uint32_t i0 = 0; i0 < L;) {  // wave-uniform
     uint32_t m = 0;                  // entries listed
     for (; i0 < L && m + 64 <= kList; i0 += 64) {
@@ -900,11 +901,13 @@ k_entry_first(const uint32_t* __restrict__ tile_first, const uint32_t* __restric
       }
       first[base + i] = f;
       mine_cnt += f;
+      if (f) mine_bytes += (uint32_t)(mine & ((1ull << kRepLenBits) - 1));
     }
     __builtin_amdgcn_wave_barrier();
   }
   mine_cnt = wave_reduce_u32(mine_cnt);
-  if (lane == 0) tile_firsts[tile] = mine_cnt;
+  mine_bytes = wave_reduce_u32(mine_bytes);  // a tile's terms are shorter than its 33 KiB window, or slow-path terms of under 16 MiB each: fits
+  if (lane == 0) { tile_firsts[tile] = mine_cnt; tile_bytes[tile] = mine_bytes; }
 }
 
 // The representatives get their ids (their rank among the representatives, i.e. ids grow with the place of a
@@ -1621,10 +1624,11 @@ k_distinct_compact(const K* __restrict__ keys, uint32_t n, const uint32_t* __res
 }
 
 // base[q] = first index whose partition field is >= q (keys sorted)
-__global__ void k_vpi_bases(const uint64_t* __restrict__ keys, uint32_t n, int shift, int nparts, uint32_t* __restrict__ base) {
+__global__ void k_vpi_bases(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_keys, int shift, int nparts,
+                            uint32_t* __restrict__ base) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q > nparts) return;
-  uint32_t lo = 0, hi = n;
+  uint32_t lo = 0, hi = *n_keys;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
     if ((keys[mid] >> shift) < (uint64_t)q) lo = mid + 1; else hi = mid;
@@ -1810,6 +1814,16 @@ __global__ void __launch_bounds__(1024) k_sum_u32(const uint32_t* __restrict__ i
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += lds[w]; *out = t; }
+}
+
+__global__ void __launch_bounds__(1024) k_sum_u32_u64(const uint32_t* __restrict__ in, uint32_t n, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long lds[16];
+  unsigned long long v = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) v += in[i];
+  v = wave_reduce_u64(v);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; ++w) t += lds[w]; *out = t; }
 }
 
 __global__ void k_pick_strided(const uint32_t* __restrict__ in, size_t stride, int n, uint32_t* __restrict__ out) {
@@ -2235,6 +2249,9 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DevBuf<uint32_t> tile_counts(pool, ntiles + 1);   // records starting in each tile; scanned: the tile's first record
   DevBuf<uint32_t> tile_leaders(pool, ntiles + 1);  // dictionary entries of each tile
   DevBuf<uint32_t> tile_firsts(pool, ntiles + 1);   // representatives per tile, then (scanned) before each tile
+  DevBuf<uint32_t> tile_bytes(pool, ntiles + 1);    // bytes of each tile's representatives
+  DevBuf<unsigned long long> d_pool_bytes(pool, 1);
+  uint64_t pool_bytes = 0;                          // all terms' bytes: comes back with the number of terms
   DevBuf<uint32_t> slot_first;                      // fused form: where each tile's slots begin
   DevBuf<uint16_t> chunk_mask;                      // two-pass form: one 16-bit start mask per 16 bytes of text
   // Dictionary entries: the tokeniser folds the occurrences of a tile onto their first one there, and only those
@@ -2353,11 +2370,14 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     DX_HIP(hipEventRecord(c1, s));
     if (n_rec)
       hipLaunchKernelGGL(k_entry_first, dim3(en_blocks), dim3(64 * EN_TILES_PER_BLOCK), 0, s, entry_first, tile_leaders.p, ntiles, text,
-                         ent.p, e_slot.p, ht.p, first.p, tile_firsts.p, coll.p);
+                         ent.p, e_slot.p, ht.p, first.p, tile_firsts.p, tile_bytes.p, coll.p);
     if (n_rec) DX_HIP(hipMemsetAsync(tile_firsts.p + ntiles, 0, 4, s));
     if (n_rec) exclusive_scan_u32_u32(pool, tile_firsts.p, tile_firsts.p, (size_t)ntiles + 1, d_total.p, s);
     else DX_HIP(hipMemsetAsync(d_total.p, 0, 4, s));
     if (n_rec) hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, s, tile_leaders.p, ntiles, d_total.p + 1);
+    if (n_rec) hipLaunchKernelGGL(k_sum_u32_u64, dim3(1), dim3(1024), 0, s, tile_bytes.p, ntiles, d_pool_bytes.p);
+    else DX_HIP(hipMemsetAsync(d_pool_bytes.p, 0, 8, s));
+    fetch.add(&pool_bytes, d_pool_bytes.p, 8);
     unsigned long long h_err = ~0ull;
     uint32_t h_coll[2] = {0, 0};
     fetch.add(&h_err, err.p, 8);
@@ -2417,16 +2437,13 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   d.ht_mask = cap - 1;
   tm.mark();  // boundary placed after the encode; tokenise/dictionary times come from their own events
   if (fused) kind_slots.reset(); else kind = std::move(kind_slots);  // two-pass form: the slots are the records
-  t_entry.reset(); e_slot.reset(); first.reset(); tile_firsts.reset(); slot_first.reset();
+  t_entry.reset(); e_slot.reset(); first.reset(); tile_firsts.reset(); tile_bytes.reset(); slot_first.reset();
 
   // ---- 4. string pool
   d.pool_off = DevBuf<uint64_t>(pool, (size_t)n_terms + 1);
   DevBuf<uint64_t> d_total64(pool, 1);
   exclusive_scan_u32_u64(pool, term_len.p, d.pool_off.p, (size_t)n_terms + 1, d_total64.p, s);
-  uint64_t pool_bytes = 0;
-  fetch.add(&pool_bytes, d_total64.p, 8);
-  fetch.sync();
-  d.pool = DevBuf<uint8_t>(pool, pool_bytes + 16);
+  d.pool = DevBuf<uint8_t>(pool, pool_bytes + 16);  // the sum of the lengths is known since the representatives were counted: no wait here
   if (n_terms) hipLaunchKernelGGL(k_pool_copy, dim3(blocks(4ull * n_terms)), dim3(256), 0, s, text, term_src.p, d.pool_off.p,
                                   (uint64_t)n_terms, d.pool.p);
   tm.mark();
@@ -2718,6 +2735,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   ps.vpi_s_base.assign(nparts + 1, 0);
   ps.vpi_o_base.assign(nparts + 1, 0);
   std::vector<uint32_t> hvb(nparts + 1, 0);
+  uint64_t n_s_host = 0;
   if (n_rows) {
     DevBuf<uint8_t> es(pool, n_rows), eo(pool, n_rows);
     const unsigned vpi_blocks = blocks(((uint64_t)n_rows + 3) / 4);  // 1024 rows each
@@ -2748,7 +2766,6 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     // The object entries are written, sorted and made distinct in words just wide enough for them: LUBM-100 needs
     // 31 bits (3 partition + 22 term + 1 role + 5 predicate), and half-width keys halve the traffic of the sort.
     const int ent_bits = bits_for(nparts) + bits_term + 1 + bits_pred;
-    uint32_t n_o = 0;
     auto object_entries = [&](auto zero) {
       using K = decltype(zero);
       DevBuf<K> ent(pool, n_o_raw);
@@ -2764,24 +2781,26 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
       DevBuf<uint32_t> dcnt(pool, (size_t)dblocks + 1);
       if (n_o_raw) hipLaunchKernelGGL(k_distinct_count<K>, dim3(dblocks), dim3(256), 0, s, ent.p, n_o_raw, dcnt.p);
       exclusive_scan_u32_u32(pool, dcnt.p, dcnt.p, n_o_raw ? dblocks : 0, d_total.p, s);
-      fetch.add(&n_o, d_total.p, 4);
-      fetch.sync();
-      ps.vpi_o = DevBuf<uint64_t>(pool, n_o);
+      // room for every entry: how many are distinct comes back with the call's last wait (the array is a few bytes per
+      // row of the partitions; an exact size would cost a host round trip here)
+      ps.vpi_o = DevBuf<uint64_t>(pool, n_o_raw);
       if (n_o_raw) hipLaunchKernelGGL(k_distinct_compact<K>, dim3(dblocks), dim3(256), 0, s, ent.p, n_o_raw, dcnt.p, ps.vpi_o.p);
     };
     if (ent_bits <= 32) object_entries((uint32_t)0); else object_entries((uint64_t)0);
     DevBuf<uint32_t> vb(pool, nparts + 1);
-    hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, n_o, bits_term + 1 + bits_pred, nparts, vb.p);
+    hipLaunchKernelGGL(k_vpi_bases, dim3(1), dim3(128), 0, s, ps.vpi_o.p, d_total.p, bits_term + 1 + bits_pred, nparts, vb.p);
     fetch.add(hvb.data(), vb.p, (nparts + 1) * 4);
     fetch.flush();  // vb ends here
-    st.n_vp_index = (uint64_t)n_s + n_o;
+    n_s_host = n_s;
   }
   tm.mark();
   fetch.sync();
   DX_HIP(hipGetLastError());
   checkpoint();  // every rank got through: all return success together
-  if (n_rows)
+  if (n_rows) {
     for (int q = 0; q <= nparts; ++q) ps.vpi_o_base[q] = hvb[q];
+    st.n_vp_index = n_s_host + hvb[nparts];  // the last base is the number of distinct object entries
+  }
 
   // ---- host-side catalogue of tables
   {
