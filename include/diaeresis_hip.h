@@ -157,11 +157,20 @@ int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const 
 int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
 
 /* ---- query processor ------------------------------------------------------------------------------ */
-/* Points the context at a layout written by dx_part_write_layout (replaces the path arithmetic of
- * QueryProcessor.loadDataset, QueryProcessor.scala:308-325) and loads its dictionary from <dataset>_data/dx_<N>/.
- * DX_E_NOENT when that directory is missing (a layout written by the Scala tools: bring its tables in with
- * dx_dictionary_load + dx_load_table_ids). */
+/* Points the context at a layout (replaces the path arithmetic of QueryProcessor.loadDataset,
+ * QueryProcessor.scala:308-325). A layout written by dx_part_write_layout carries its dictionary and id columns under
+ * <dataset>_data/dx_<N>/: the dictionary is loaded from there and tables come in one by one with dx_load_table. A layout
+ * without that directory (written by the Scala tools) is brought in through dx_import_layout. */
 int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions);
+/* Reads every vertical-partition table of a layout from its Parquet files,
+ * <base><dataset>_data/cluster/clusters_<N>_bal/<PPPPP>/_3=<predicate>/part-*.parquet with the string columns _1, _2
+ * (DAP.scala:433-437): what spark.read.load(...).as[(String, String)] does table by table in
+ * QueryProcessor.loadDataset (QueryProcessor.scala:322-333), here for all tables at once, because one dictionary is
+ * built over their strings. Reads what parquet-mr (Spark) and dx_part_write_layout write: REQUIRED or OPTIONAL
+ * BYTE_ARRAY columns without nulls, PLAIN and dictionary encodings, data pages of both versions, uncompressed or
+ * snappy. Afterwards the tables are resident as id columns and dx_load_table / dx_unload_all hand them out and take
+ * them back by key without reading anything again. n_tables / n_rows (may be null): what was read. */
+int dx_import_layout(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions, uint64_t* n_tables, uint64_t* n_rows);
 /* Replaces QueryProcessor.loadDataset + preloadTables (QueryProcessor.scala:210-236, 308-339) for one
  * entry of the `partitions` line ("00001-_3=<sanitised predicate>"): makes the table resident in HBM and
  * visible to SQL under "table" + key with '-' -> '_' and '=' -> '_E_' (:216). Memoised like dataMap (:327-337). */

@@ -723,15 +723,167 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
   });
 }
 
+}  // extern "C"
+
+// ---- a layout's Parquet files -> dictionary + resident tables --------------------------------------------------
+namespace {
+// Distinct strings in the order they are first seen; id = position.
+struct HostTerms {
+  std::string bytes;
+  std::vector<uint64_t> off{0};
+  std::vector<uint64_t> hashes;   // per id
+  std::vector<uint32_t> slots;    // id + 1, open addressing, a power of two
+  HostTerms() : slots(1u << 16, 0) {}
+  uint32_t intern(const uint8_t* p, uint32_t len) {
+    const uint64_t h = hash_bytes(p, len, 0x9E3779B97F4A7C15ull);
+    size_t mask = slots.size() - 1, at = (size_t)h & mask;
+    for (;; at = (at + 1) & mask) {
+      const uint32_t v = slots[at];
+      if (!v) break;
+      const uint32_t id = v - 1;
+      if (hashes[id] == h && off[id + 1] - off[id] == len && memcmp(bytes.data() + off[id], p, len) == 0) return id;
+    }
+    if (hashes.size() >= 0xFFFFFFF0ull) throw DxError(DX_E_RANGE, "more than 2^32 terms");
+    const uint32_t id = (uint32_t)hashes.size();
+    bytes.append(reinterpret_cast<const char*>(p), len);
+    off.push_back(bytes.size());
+    hashes.push_back(h);
+    slots[at] = id + 1;
+    if (hashes.size() * 2 > slots.size()) {  // keep it at most half full
+      std::vector<uint32_t> bigger(slots.size() * 2, 0);
+      mask = bigger.size() - 1;
+      for (uint32_t i = 0; i < (uint32_t)hashes.size(); ++i) {
+        size_t a = (size_t)hashes[i] & mask;
+        while (bigger[a]) a = (a + 1) & mask;
+        bigger[a] = i + 1;
+      }
+      slots.swap(bigger);
+    }
+    return id;
+  }
+};
+// One table's two columns as ids: a dictionary page is looked up string by string, its rows only through the page's map.
+struct ImportSink : ParquetStringSink {
+  HostTerms& terms;
+  std::vector<uint32_t> map[2];
+  std::vector<int64_t> ids[2];
+  explicit ImportSink(HostTerms& t) : terms(t) {}
+  void dictionary(int col, const std::vector<std::pair<const uint8_t*, uint32_t>>& values) override {
+    map[col].resize(values.size());
+    for (size_t i = 0; i < values.size(); ++i) map[col][i] = terms.intern(values[i].first, values[i].second);
+  }
+  void indices(int col, const uint32_t* idx, size_t n) override {
+    const size_t at = ids[col].size();
+    ids[col].resize(at + n);
+    for (size_t i = 0; i < n; ++i) ids[col][at + i] = map[col][idx[i]];
+  }
+  void value(int col, const uint8_t* bytes, uint32_t len) override { ids[col].push_back(terms.intern(bytes, len)); }
+  void end_of_chunk(int) override {}
+};
+std::vector<std::string> list_dir(const std::string& dir) {
+  std::vector<std::string> out;
+  DIR* dp = opendir(dir.c_str());
+  if (!dp) throw DxError(DX_E_NOENT, "cannot open " + dir);
+  while (dirent* e = readdir(dp)) out.emplace_back(e->d_name);
+  closedir(dp);
+  std::sort(out.begin(), out.end());
+  return out;
+}
+bool is_dir(const std::string& p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+bool ends_with(const std::string& s, const char* suffix) {
+  const size_t n = strlen(suffix);
+  return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+void install_dictionary(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n_terms) {
+  ctx->catalog.clear();
+  ctx->table_stats.clear();
+  ctx->imported.clear();
+  ctx->part = PartitionState();
+  Dictionary nd;
+  nd.n_terms = n_terms;
+  nd.seed = 0x243F6A8885A308D3ull;
+  nd.pool_off = DevBuf<uint64_t>(ctx->pool, n_terms + 1);
+  nd.pool = DevBuf<uint8_t>(ctx->pool, offsets[n_terms] + 16);
+  DX_HIP(hipMemcpy(nd.pool_off.p, offsets, (n_terms + 1) * 8, hipMemcpyHostToDevice));
+  if (offsets[n_terms]) DX_HIP(hipMemcpy(nd.pool.p, bytes, offsets[n_terms], hipMemcpyHostToDevice));
+  ctx->dict = std::move(nd);
+  dict_build_table(ctx);  // fails if two terms are equal
+}
+
+// Every vertical-partition table of <base><dataset>_data/cluster/clusters_<N>_bal/<PPPPP>/_3=<predicate>/part-*.parquet
+// (columns _1, _2: DAP.scala:433-437), the way QueryProcessor.loadDataset reads them (QueryProcessor.scala:308-339),
+// all at once: one dictionary over their strings, the tables resident as id columns under their "PPPPP-_3=<dir>" keys.
+void import_layout(dx_ctx* ctx, const std::string& B, const std::string& D, int n_partitions, uint64_t* n_tables, uint64_t* n_rows) {
+  const std::string root = B + D + "_data/cluster/clusters_" + std::to_string(n_partitions) + "_bal";
+  if (!is_dir(root)) throw DxError(DX_E_NOENT, root + " not found");
+  HostTerms terms;
+  struct Pending { std::string key; std::vector<int64_t> s, o; bool several_files; };
+  std::vector<Pending> pending;
+  uint64_t rows_total = 0;
+  for (const std::string& part : list_dir(root)) {
+    if (part.size() != 5 || part.find_first_not_of("0123456789") != std::string::npos || !is_dir(root + "/" + part)) continue;
+    for (const std::string& sub : list_dir(root + "/" + part)) {
+      if (sub.compare(0, 3, "_3=") != 0 || !is_dir(root + "/" + part + "/" + sub)) continue;
+      const std::string dir = root + "/" + part + "/" + sub;
+      ImportSink sink(terms);
+      int files = 0;
+      for (const std::string& f : list_dir(dir)) {
+        if (!ends_with(f, ".parquet") || f[0] == '.' || f[0] == '_') continue;
+        read_parquet_strings(dir + "/" + f, {"_1", "_2"}, sink);
+        ++files;
+      }
+      if (sink.ids[0].size() != sink.ids[1].size()) throw DxError(DX_E_MALFORMED, "columns of different lengths in " + dir);
+      if (sink.ids[0].size() >= (1ull << 32)) throw DxError(DX_E_RANGE, "table with 2^32 rows or more: " + dir);
+      rows_total += sink.ids[0].size();
+      pending.push_back({part + "-" + sub, std::move(sink.ids[0]), std::move(sink.ids[1]), files > 1});
+    }
+  }
+  install_dictionary(ctx, terms.bytes.data(), terms.off.data(), terms.hashes.size());
+  for (Pending& t : pending) {
+    dx_ctx::ImportedTable it;
+    it.rows = t.s.size();
+    it.several_files = t.several_files;
+    it.s = DevBuf<int64_t>(ctx->pool, it.rows);
+    it.o = DevBuf<int64_t>(ctx->pool, it.rows);
+    if (it.rows) {
+      DX_HIP(hipMemcpy(it.s.p, t.s.data(), it.rows * 8, hipMemcpyHostToDevice));
+      DX_HIP(hipMemcpy(it.o.p, t.o.data(), it.rows * 8, hipMemcpyHostToDevice));
+    }
+    ctx->imported.emplace(t.key, std::move(it));
+    std::vector<int64_t>().swap(t.s);
+    std::vector<int64_t>().swap(t.o);
+  }
+  ctx->ds_base = B;
+  ctx->ds_name = D;
+  ctx->ds_partitions = n_partitions;
+  if (n_tables) *n_tables = pending.size();
+  if (n_rows) *n_rows = rows_total;
+}
+}  // namespace
+
+extern "C" {
+
+int dx_import_layout(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions, uint64_t* n_tables, uint64_t* n_rows) {
+  return guard(ctx, [&] {
+    if (!dataset) throw DxError(DX_E_INVAL, "null dataset");
+    import_layout(ctx, norm_base(base), dataset, n_partitions, n_tables, n_rows);
+  });
+}
+
 int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_partitions) {
   return guard(ctx, [&] {
     if (!dataset) throw DxError(DX_E_INVAL, "null dataset");
     const std::string B = norm_base(base), D = dataset;
     const std::string dd = B + D + "_data/dx_" + std::to_string(n_partitions) + "/dictionary";
     struct stat sdd;
-    if (stat(dd.c_str(), &sdd) != 0)
-      throw DxError(DX_E_NOENT, dd + " not found: a layout written by dx_part_write_layout carries its dictionary and id columns there; "
-                                     "tables written by the Scala tools are loaded with dx_dictionary_load + dx_load_table_ids");
+    if (stat(dd.c_str(), &sdd) != 0) {  // a layout written by the Scala tools: its Parquet files are all there is
+      import_layout(ctx, B, D, n_partitions, nullptr, nullptr);
+      return;
+    }
     const std::string offs = read_file(dd + "/offsets.bin"), terms = read_file(dd + "/terms.bin");
     if (offs.size() < 8 || offs.size() % 8) throw DxError(DX_E_IO, "corrupt dictionary offsets");
     {  // the kernels index the term pool by these: they must start at 0, never decrease and end at the pool's size
@@ -744,6 +896,7 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
     }
     ctx->catalog.clear();
     ctx->table_stats.clear();
+    ctx->imported.clear();
     ctx->part = PartitionState();
     Dictionary nd;
     nd.n_terms = offs.size() / 8 - 1;
@@ -834,6 +987,14 @@ static CatalogTable& register_table(dx_ctx* ctx, const char* partition_key) {
           resident = true;
         }
       }
+      if (!resident) {
+        auto im = ctx->imported.find(key);
+        if (im != ctx->imported.end()) {  // brought in from Parquet: the columns are in HBM already
+          t.slices.push_back({im->second.s.p, im->second.o.p, im->second.rows});
+          t.several_sources = im->second.several_files;  // several part files can hold a row twice, like several predicates in one directory
+          resident = true;
+        }
+      }
       if (resident) {
         if (t.slices.size() == 1) {
           t.s = t.slices[0].s; t.o = t.slices[0].o; t.rows = t.slices[0].rows;
@@ -899,18 +1060,7 @@ int dx_dictionary_load(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, 
     for (uint64_t i = 0; i < n_terms; ++i)
       if (offsets[i + 1] < offsets[i]) throw DxError(DX_E_INVAL, "offsets must not decrease");
     if (offsets[0] != 0) throw DxError(DX_E_INVAL, "offsets[0] must be 0");
-    ctx->catalog.clear();
-    ctx->table_stats.clear();
-    ctx->part = PartitionState();
-    Dictionary nd;
-    nd.n_terms = n_terms;
-    nd.seed = 0x243F6A8885A308D3ull;
-    nd.pool_off = DevBuf<uint64_t>(ctx->pool, n_terms + 1);
-    nd.pool = DevBuf<uint8_t>(ctx->pool, offsets[n_terms] + 16);
-    DX_HIP(hipMemcpy(nd.pool_off.p, offsets, (n_terms + 1) * 8, hipMemcpyHostToDevice));
-    if (offsets[n_terms]) DX_HIP(hipMemcpy(nd.pool.p, bytes, offsets[n_terms], hipMemcpyHostToDevice));
-    ctx->dict = std::move(nd);
-    dict_build_table(ctx);  // fails if two terms are equal
+    install_dictionary(ctx, bytes, offsets, n_terms);
     ctx->ds_base.clear();
     ctx->ds_name.clear();
   });

@@ -2230,6 +2230,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   if (n_bytes >= (1ull << (64 - kRepLenBits))) throw DxError(DX_E_RANGE, "input larger than 1 TiB");
   ctx->catalog.clear();
   ctx->table_stats.clear();
+  ctx->imported.clear();
   ctx->part = PartitionState();
   ctx->measures = MeasureState();
   ctx->dict = Dictionary();

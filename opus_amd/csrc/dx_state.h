@@ -127,6 +127,10 @@ struct dx_ctx {
   dx::MeasureState measures;
   std::map<std::string, dx::CatalogTable> catalog;   // by view name
   std::map<std::string, std::pair<uint64_t, uint64_t>> table_stats;  // by table key: distinct s, distinct o
+  // Vertical-partition tables brought in from a layout's Parquet files (dx_import_layout), by table key: resident id
+  // columns that dx_load_table hands out without copying, like the tables of a partition run.
+  struct ImportedTable { dx::DevBuf<int64_t> s, o; uint64_t rows = 0; bool several_files = false; };
+  std::map<std::string, ImportedTable> imported;
   // dataset opened from disk
   std::string ds_base, ds_name;
   int ds_partitions = 0;
@@ -303,6 +307,18 @@ struct dx_result {
 };
 
 namespace dx {
+// dx_parquet_read.cpp: the string columns of one Parquet file, handed over the way the file holds them: per column chunk
+// a dictionary and runs of indices into it (or single values where a page is not dictionary-encoded). Columns are
+// delivered chunk by chunk, column after column inside a row group; rows of different columns line up by position.
+struct ParquetStringSink {
+  virtual ~ParquetStringSink() = default;
+  virtual void dictionary(int col, const std::vector<std::pair<const uint8_t*, uint32_t>>& values) = 0;  // valid during the call
+  virtual void indices(int col, const uint32_t* idx, size_t n) = 0;       // rows that name entries of the column's last dictionary
+  virtual void value(int col, const uint8_t* bytes, uint32_t len) = 0;    // one row of a page without dictionary
+  virtual void end_of_chunk(int col) = 0;
+};
+void read_parquet_strings(const std::string& path, const std::vector<std::string>& columns, ParquetStringSink& sink);
+
 // dx_parquet.cpp: files of REQUIRED string columns as the reference's Spark jobs write them (schemas of
 // utils/Types.scala:7-16). A column is given as term ids over a string pool, or as strings.
 class ParquetWriter {

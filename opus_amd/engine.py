@@ -34,7 +34,7 @@ EXPORTS = [
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
     "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
     "dx_query_count_noalloc", "dx_rccl_unique_id", "dx_comm_rccl_init", "dx_comm_rccl_init_file", "dx_comm_selftest",
-    "dx_load_tables_sharded",
+    "dx_load_tables_sharded", "dx_import_layout",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library():
         "dx_measures_write": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
         "dx_part_write_layout": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
         "dx_open_dataset": (c_int, [c_void_p, c_char_p, c_char_p, c_int]),
+        "dx_import_layout": (c_int, [c_void_p, c_char_p, c_char_p, c_int, u64p, u64p]),
         "dx_load_table": (c_int, [c_void_p, c_char_p, u64p]),
         "dx_load_tables": (c_int, [c_void_p, POINTER(c_char_p), c_int, u64p]),
         "dx_unload_all": (c_int, [c_void_p]),
@@ -366,6 +367,13 @@ class Engine:
     # ---- query processor ---------------------------------------------------------------
     def open_dataset(self, base: str, dataset: str, n_partitions: int):
         self._check(self.lib.dx_open_dataset(self.ctx, base.encode(), dataset.encode(), n_partitions))
+
+    def import_layout(self, base: str, dataset: str, n_partitions: int):
+        """Every vertical-partition table of a layout from its Parquet files (the library's own reader): one dictionary
+        over their strings, the tables resident by key. Returns (tables, rows)."""
+        nt, nr = c_uint64(0), c_uint64(0)
+        self._check(self.lib.dx_import_layout(self.ctx, base.encode(), dataset.encode(), n_partitions, byref(nt), byref(nr)))
+        return nt.value, nr.value
 
     def load_table(self, key: str) -> int:
         rows = c_uint64(0)

@@ -151,3 +151,111 @@ def test_native_parquet_writer_is_read_back_by_pyarrow(tmp_path):
         a, b, c = t["_1"].to_pylist(), t["_2"].to_pylist(), t["parts"].to_pylist()
         for i in list(range(0, rows, 9973)) + [x for x in (1, rows - 1, (1 << 20) - 1, 1 << 20) if 0 <= x < rows]:
             assert a[i] == term(i % T) and b[i] == term((7 * i + 3) % T) and c[i] == "row%d" % i, i
+
+
+def _read_with_harness(exe, path, cols, tmp_path):
+    import subprocess
+    out = str(tmp_path / "dump.txt")
+    r = subprocess.run([exe, path, out] + cols, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return None, r.stderr
+    data = open(out, "rb").read()
+    per_col = [[] for _ in cols]
+    at = 0
+    summary = None
+    while at < len(data):
+        if data.startswith(b"chunks ", at):
+            summary = data[at:].decode().split()
+            break
+        t1 = data.index(b"\t", at)
+        t2 = data.index(b"\t", t1 + 1)
+        col, n = int(data[at:t1]), int(data[t1 + 1:t2])
+        per_col[col].append(data[t2 + 1:t2 + 1 + n])
+        at = t2 + 1 + n + 1
+    return per_col, dict(zip(summary[0::2], map(int, summary[1::2])))
+
+
+def test_native_parquet_reader_reads_what_spark_style_writers_write(tmp_path):
+    """The library's own reader (opus_amd/csrc/dx_parquet_read.cpp, host code), driven without a GPU by a small
+    harness built with AddressSanitizer, against files written by pyarrow's parquet-cpp in the shapes a layout can
+    come in: snappy and uncompressed, dictionary pages and plain pages (and the fall-back from one to the other inside
+    a chunk), data pages of both versions, nullable and required columns, several row groups, small pages, an empty
+    file; and against the library's own writer. Unsupported things are refused, not misread."""
+    import subprocess
+
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pqr")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+           "-I/opt/rocm/include", "-I" + os.path.join(root, "opus_amd", "csrc"), "-I" + os.path.join(root, "include"), "-o", exe,
+           os.path.join(root, "tests", "native", "parquet_reader_harness.cpp"), os.path.join(root, "opus_amd", "csrc", "dx_parquet_read.cpp")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if p.returncode != 0:
+        pytest.skip("host build of the reader harness failed: " + p.stderr[-400:])
+    rng = np.random.default_rng(5)
+    n = 200000
+    terms = ['"h\u00e9llo \U0001F642"@fr', "", "<a>"] + ["<http://example.org/t%d>" % k + "y" * (k % 61) for k in range(30000)]
+    s = [terms[i] for i in rng.integers(0, len(terms), n)]
+    o = [terms[i] for i in rng.integers(0, 40, n)]                      # few distinct values: narrow indices, long runs
+    u = ["<unique/%d>" % i + "z" * (i % 300) for i in range(n)]          # all distinct: the writer gives the dictionary up
+    table = pa.table({"_1": s, "_2": o, "extra": u})
+    required = pa.schema([pa.field(name, pa.string(), nullable=False) for name in ("_1", "_2", "extra")])
+    cases = {
+        "snappy_v1": dict(compression="snappy", data_page_version="1.0", row_group_size=70000),
+        "plain_v1": dict(compression="none", use_dictionary=False, data_page_version="1.0"),
+        "snappy_v2": dict(compression="snappy", data_page_version="2.0", data_page_size=4096),
+        "none_v2_smalldict": dict(compression="none", data_page_version="2.0", dictionary_pagesize_limit=20000, row_group_size=50000),
+    }
+    want = [[x.encode() for x in col] for col in (s, o, u)]
+    for name, kw in cases.items():
+        for label, tab in (("nullable", table), ("required", table.cast(required))):
+            path = str(tmp_path / (name + "_" + label + ".parquet"))
+            pq.write_table(tab, path, **kw)
+            got, info = _read_with_harness(exe, path, ["_1", "_2", "extra"], tmp_path)
+            assert got is not None, (name, label, info)
+            assert got == want, (name, label)
+            assert info["indexed"] + info["plain"] == 3 * n
+            if name == "plain_v1":
+                assert info["dictionaries"] == 0 and info["indexed"] == 0
+            else:
+                assert info["dictionaries"] >= 3 and info["indexed"] >= n and info["plain"] >= n  # `extra` gives its dictionary up
+    # column order and a subset of the columns
+    got, _ = _read_with_harness(exe, str(tmp_path / "snappy_v1_nullable.parquet"), ["_2", "_1"], tmp_path)
+    assert got == [want[1], want[0]]
+    # no rows
+    pq.write_table(table.slice(0, 0), str(tmp_path / "empty.parquet"), compression="snappy")
+    got, info = _read_with_harness(exe, str(tmp_path / "empty.parquet"), ["_1", "_2"], tmp_path)
+    assert got == [[], []]
+    # the library's own writer
+    wexe = str(tmp_path / "pqw")
+    cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "opus_amd", "csrc"),
+           "-I" + os.path.join(root, "include"), "-o", wexe, os.path.join(root, "tests", "native", "parquet_writer_harness.cpp"),
+           os.path.join(root, "opus_amd", "csrc", "dx_parquet.cpp")]
+    assert subprocess.run(cmd, capture_output=True, text=True, timeout=300).returncode == 0
+    own = str(tmp_path / "own.parquet")
+    assert subprocess.run([wexe, own, "1200000", "5000"], capture_output=True, timeout=300).returncode == 0
+    got, info = _read_with_harness(exe, own, ["_1", "_2", "parts"], tmp_path)
+    t = pq.read_table(own)
+    assert got == [[x.encode() for x in t[c].to_pylist()] for c in ("_1", "_2", "parts")]
+    # refused: a null, a codec that is not read, a column that is not a string, a column that is not there, not a Parquet file
+    pq.write_table(pa.table({"_1": ["a", None], "_2": ["b", "c"]}), str(tmp_path / "null.parquet"))
+    got, err = _read_with_harness(exe, str(tmp_path / "null.parquet"), ["_1", "_2"], tmp_path)
+    assert got is None and "null" in err
+    pq.write_table(table.slice(0, 10), str(tmp_path / "gzip.parquet"), compression="gzip")
+    got, err = _read_with_harness(exe, str(tmp_path / "gzip.parquet"), ["_1"], tmp_path)
+    assert got is None and "codec" in err
+    pq.write_table(pa.table({"_1": [1, 2]}), str(tmp_path / "ints.parquet"))
+    got, err = _read_with_harness(exe, str(tmp_path / "ints.parquet"), ["_1"], tmp_path)
+    assert got is None and "not a string column" in err
+    got, err = _read_with_harness(exe, str(tmp_path / "ints.parquet"), ["nope"], tmp_path)
+    assert got is None and "no column" in err
+    open(str(tmp_path / "junk.parquet"), "wb").write(b"PAR1 this is not a parquet file PAR1")
+    got, err = _read_with_harness(exe, str(tmp_path / "junk.parquet"), ["_1"], tmp_path)
+    assert got is None
+    # truncated files never read outside the mapping (the harness runs under AddressSanitizer)
+    blob = open(str(tmp_path / "snappy_v1_nullable.parquet"), "rb").read()
+    for cut in (len(blob) // 3, len(blob) - 9, len(blob) - 100):
+        open(str(tmp_path / "cut.parquet"), "wb").write(blob[:cut] + blob[-8:])
+        got, err = _read_with_harness(exe, str(tmp_path / "cut.parquet"), ["_1", "_2"], tmp_path)
+        assert got is None and "AddressSanitizer" not in err, err[-300:]

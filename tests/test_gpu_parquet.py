@@ -45,3 +45,79 @@ def test_export_import_round_trip(tmp_path, lubm1):
             e2.load_table_ids("00000-_3=x", np.array([10 ** 9]), np.array([0]))  # id outside the dictionary
     finally:
         e2.close()
+
+
+def test_native_import_of_a_layout_written_the_way_spark_writes_it(tmp_path, lubm1):
+    """The library reads a layout's Parquet files itself (dx_import_layout; dx_open_dataset falls back to it when the
+    layout has no id columns beside it): its own files, and the same tables rewritten the way Spark leaves them --
+    snappy, nullable columns, several part files per directory, no dx_<N> directory. Counts and bindings equal the
+    oracle's; tables come and go by key without being read again."""
+    import shutil
+
+    import pyarrow.parquet as pq
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_BINDINGS, Engine
+    from opus_amd.host import parquet_io as P, translator as T
+    from oracle.query_oracle import parse_translated_file, run_query
+    ref = lubm1["oracle"]
+    base = str(tmp_path / "own") + "/"
+    os.makedirs(base)
+    e = Engine(0)
+    try:
+        e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+        e.write_layout(base, "lubm", str(tmp_path / "own"))
+    finally:
+        e.close()
+    # the same layout as Spark would have left it
+    spark = str(tmp_path / "spark") + "/"
+    src_root, dst_root = P.cluster_dir(base, "lubm", 4), P.cluster_dir(spark, "lubm", 4)
+    n_rows = 0
+    for key in P.vp_table_keys(base, "lubm", 4):
+        part, sub = key.split("-", 1)
+        t = P.read_table(os.path.join(src_root, part, sub))
+        n_rows += t.num_rows
+        d = os.path.join(dst_root, part, sub)
+        os.makedirs(d)
+        half = t.num_rows // 2
+        pieces = [t.slice(0, half), t.slice(half)] if t.num_rows > 3 else [t]
+        for i, piece in enumerate(pieces):
+            pq.write_table(piece, os.path.join(d, "part-%05d-4e0c-c000.snappy.parquet" % i), compression="snappy", data_page_version="1.0")
+        open(os.path.join(d, "_SUCCESS"), "w").close()
+        open(os.path.join(d, ".part-00000-4e0c-c000.snappy.parquet.crc"), "wb").write(b"crc")
+    assert not os.path.exists(os.path.join(spark, "lubm_data", "dx_4"))
+
+    ni = {}
+    for u, c in ref["node_index"]:
+        ni.setdefault(u, []).append(c)
+    cidx = T.load_class_index(lubm1["class_index"])
+    for how in ("own files, dx_import_layout", "spark files, dx_open_dataset"):
+        e2 = Engine(0)
+        try:
+            if how.startswith("own"):
+                tables, rows = e2.import_layout(base, "lubm", 4)
+                assert (tables, rows) == (len(ref["vp"]), n_rows)
+            else:
+                e2.open_dataset(spark, "lubm", 4)
+            for name in ("Q2.txt", "Q4.txt", "Q7.txt", "Q9.txt", "Q14.txt"):
+                tr = T.translate_query(name, lubm.queries(0)[name], lambda u: ni.get(u, []), cidx, ref["partition_stat"])
+                want = run_query(ref["vp"], tr)
+                qm, parts, _ = parse_translated_file(tr)
+                for again in range(2):  # unloadTables, then the same tables by key once more: nothing is read again
+                    e2.unload_all()
+                    assert sum(e2.load_table(p) for p in parts) == want["load_data"], (how, name)
+                    res = e2.query(next(iter(qm.values())), DX_QUERY_BINDINGS)
+                    got, cols = res.rows()
+                    assert res.count == want["count"] and cols == want["columns"] and got == want["rows"], (how, name)
+                    res.close()
+            with pytest.raises(Exception):
+                e2.load_table("00000-_3=no_such_predicate")
+        finally:
+            e2.close()
+    # a layout that is not there
+    e3 = Engine(0)
+    try:
+        with pytest.raises(Exception):
+            e3.import_layout(str(tmp_path / "nowhere") + "/", "lubm", 4)
+    finally:
+        e3.close()
+    shutil.rmtree(str(tmp_path / "spark"))
