@@ -433,12 +433,15 @@ void read_parquet_strings(const std::string& path, const std::vector<std::string
             e = b + dict_bytes.size();
           }
           dict.clear();
+          if (h.num_values < 0 || (int64_t)h.num_values * 4 > e - b) bad(path, "dictionary page with " + std::to_string(h.num_values) + " values");
           plain_byte_arrays(b, e, h.num_values, path, [&](const uint8_t* p, uint32_t len) { dict.emplace_back(p, len); });
           have_dict = true;
           sink.dictionary((int)c, dict);
           continue;
         }
         if (h.type != kDataPage && h.type != kDataPageV2) continue;  // index pages and the like
+        // a page of parquet-mr holds some ten thousand values, one of this library's writer 2^20: a damaged header must not size buffers
+        if (h.num_values < 0 || h.num_values > (1 << 26) || h.num_values > left) bad(path, "page with " + std::to_string(h.num_values) + " values");
         const uint8_t* vals;
         const uint8_t* vend;
         size_t present = (size_t)h.num_values;

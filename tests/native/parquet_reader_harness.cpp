@@ -45,6 +45,9 @@ int main(int argc, char** argv) {
   } catch (const dx::DxError& e) {
     fprintf(stderr, "%d %s\n", e.code, e.what());
     rc = 1;
+  } catch (const std::exception& e) {  // the library's entry points turn these into error codes as well
+    fprintf(stderr, "exception %s\n", e.what());
+    rc = 1;
   }
   fclose(f);
   return rc;

@@ -253,7 +253,20 @@ def test_native_parquet_reader_reads_what_spark_style_writers_write(tmp_path):
     open(str(tmp_path / "junk.parquet"), "wb").write(b"PAR1 this is not a parquet file PAR1")
     got, err = _read_with_harness(exe, str(tmp_path / "junk.parquet"), ["_1"], tmp_path)
     assert got is None
-    # truncated files never read outside the mapping (the harness runs under AddressSanitizer)
+    # damaged files: any outcome but a memory error (the harness runs under AddressSanitizer and UBSan)
+    small = str(tmp_path / "small.parquet")
+    pq.write_table(table.slice(0, 3000), small, compression="snappy", data_page_size=2048, row_group_size=1000)
+    good = bytearray(open(small, "rb").read())
+    footer_len = int.from_bytes(good[-8:-4], "little")
+    for trial in range(300):
+        b = bytearray(good)
+        lo = len(b) - 8 - footer_len if trial % 2 else 4          # every other trial damages the footer
+        for _ in range(1 + trial % 3):
+            b[int(rng.integers(lo, len(b) - 8))] = int(rng.integers(0, 256))
+        open(str(tmp_path / "fuzz.parquet"), "wb").write(bytes(b))
+        r = subprocess.run([exe, str(tmp_path / "fuzz.parquet"), str(tmp_path / "fuzz.txt"), "_1", "_2", "extra"], capture_output=True, text=True, timeout=120)
+        assert r.returncode in (0, 1) and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (trial, r.stderr[-400:])
+    # truncated files never read outside the mapping
     blob = open(str(tmp_path / "snappy_v1_nullable.parquet"), "rb").read()
     for cut in (len(blob) // 3, len(blob) - 9, len(blob) - 100):
         open(str(tmp_path / "cut.parquet"), "wb").write(blob[:cut] + blob[-8:])
