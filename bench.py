@@ -152,7 +152,7 @@ def file_leg(eng, arr, text, n_bytes, class_index, n_partitions):
                 "file_GBps": n_bytes / t_file / 1e9,
                 "write_layout_ms": t_layout * 1e3, "layout_bytes": size,
                 "note": "file in the page cache -> pinned staging (2 x 64 MiB, read and upload overlapped) -> HBM -> partitions; "
-                        "then Parquet (dictionary pages, uncompressed) + id columns + text files on local disk, one host thread"}
+                        "then Parquet (dictionary pages, uncompressed) + id columns + text files on local disk, the files encoded and written by up to 16 host threads"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
