@@ -645,7 +645,8 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
     // digits after "part-" (DAP.scala:427-428). One id per call stands in for the job's uuid.
     char job[64];
     snprintf(job, sizeof job, "%08x-dx00-4000-8000-%012llx", (unsigned)time(nullptr), (unsigned long long)(uintptr_t)ctx & 0xFFFFFFFFFFFFull);
-    auto part_file = [&](int k) { return "part-" + part_name(k) + "-" + job + "-c000.parquet"; };
+    const std::string suffix = parquet_writer_uses_snappy() ? "-c000.snappy.parquet" : "-c000.parquet";
+    auto part_file = [&](int k) { return "part-" + part_name(k) + "-" + job + suffix; };
     // The files are independent of each other: this thread fetches each file's id columns from the device and makes
     // the directories, a pool of host threads encodes and writes (one thread took 6.1 s for LUBM-100's 5.6 GB).
     std::vector<std::pair<uint64_t, std::function<void()>>> jobs;  // (values, work)

@@ -6,9 +6,12 @@
 // QueryProcessor.scala:308-339) and any other Parquet reader accept them: format version 1, one row group per
 // kRowGroupRows rows, REQUIRED BYTE_ARRAY columns annotated UTF8, per column chunk one dictionary page (PLAIN) and
 // one data page of bit-packed dictionary indices (the PLAIN_DICTIONARY encoding of parquet-mr's first-version
-// pages), no compression, Thrift compact footer. Terms repeat heavily inside a column, so the dictionary pages keep
-// the files near the size of Spark's own (which adds snappy on top).
+// pages), Thrift compact footer. Terms repeat heavily inside a column, so the dictionary pages keep the files near
+// the size of Spark's own. Pages are uncompressed unless DX_PARQUET_CODEC=snappy asks for Spark's default codec
+// (a third of the bytes on disk for LUBM's tables, and the encoding takes about twice as long).
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "dx_state.h"
@@ -48,21 +51,82 @@ struct Thrift {
   void elem_str(const std::string& s) { varint(s.size()); out += s; }
 };
 
-constexpr int kByteArray = 6, kRequired = 0, kUtf8 = 0, kPlain = 0, kPlainDictionary = 2, kRle = 3, kUncompressed = 0;
+constexpr int kByteArray = 6, kRequired = 0, kUtf8 = 0, kPlain = 0, kPlainDictionary = 2, kRle = 3, kUncompressed = 0, kSnappy = 1;
 constexpr int kDataPage = 0, kDictionaryPage = 2;
 constexpr uint64_t kRowGroupRows = 1u << 20;
 
 struct ChunkMeta {
-  int64_t dict_offset, data_offset, total_size, num_values;
+  int64_t dict_offset, data_offset, total_size, total_uncompressed, num_values;
 };
 
 void put_u32(std::string& s, uint32_t v) { s.append(reinterpret_cast<const char*>(&v), 4); }
 
-std::string page_header(int type, size_t size, uint64_t num_values, bool dictionary_encoded) {
+// ---- Snappy, raw format: the uncompressed length, then literals and copies found with a 4-byte hash inside 64 KiB blocks ----
+inline uint32_t load32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+void snappy_literal(std::string& out, const uint8_t* p, size_t len) {
+  if (!len) return;
+  const size_t n = len - 1;
+  if (n < 60) {
+    out.push_back((char)(n << 2));
+  } else {
+    const int bytes = n < (1u << 8) ? 1 : n < (1u << 16) ? 2 : n < (1u << 24) ? 3 : 4;
+    out.push_back((char)((59 + bytes) << 2));
+    for (int i = 0; i < bytes; ++i) out.push_back((char)(n >> (8 * i)));
+  }
+  out.append(reinterpret_cast<const char*>(p), len);
+}
+void snappy_copy(std::string& out, size_t offset, size_t len) {  // len >= 4, offset < 65536
+  auto two = [&](size_t l) { out.push_back((char)(2 | ((l - 1) << 2))); out.push_back((char)offset); out.push_back((char)(offset >> 8)); };
+  while (len >= 68) { two(64); len -= 64; }
+  if (len > 64) { two(60); len -= 60; }
+  if (len < 12 && offset < 2048) { out.push_back((char)(1 | ((len - 4) << 2) | ((offset >> 8) << 5))); out.push_back((char)offset); }
+  else two(len);
+}
+void snappy_compress(const std::string& in, std::string& out) {
+  out.clear();
+  for (uint64_t v = in.size();;) {  // the length as a varint
+    if (v >= 0x80) { out.push_back((char)(v | 0x80)); v >>= 7; } else { out.push_back((char)v); break; }
+  }
+  constexpr size_t kBlock = 1 << 16;
+  std::vector<uint16_t> table(1 << 14);
+  const uint8_t* base = reinterpret_cast<const uint8_t*>(in.data());
+  for (size_t b0 = 0; b0 < in.size(); b0 += kBlock) {
+    const uint8_t* p = base + b0;
+    const size_t len = std::min(kBlock, in.size() - b0);
+    std::fill(table.begin(), table.end(), (uint16_t)0);
+    size_t ip = 0, lit = 0;
+    uint32_t skip = 32;  // after 32 positions without a match the step grows: bit-packed indices do not compress
+    while (ip + 4 <= len) {
+      const uint32_t w = load32(p + ip);
+      const uint32_t h = (w * 0x1E35A7BDu) >> 18;
+      const size_t cand = table[h];
+      table[h] = (uint16_t)ip;
+      if (cand < ip && load32(p + cand) == w) {
+        snappy_literal(out, p + lit, ip - lit);
+        size_t m = 4;
+        while (ip + m < len && p[cand + m] == p[ip + m]) ++m;
+        snappy_copy(out, ip - cand, m);
+        ip += m;
+        lit = ip;
+        skip = 32;
+      } else {
+        ip += skip++ >> 5;
+      }
+    }
+    snappy_literal(out, p + lit, len - lit);
+  }
+}
+
+bool snappy_pages() {
+  const char* e = getenv("DX_PARQUET_CODEC");
+  return e && std::string(e) == "snappy";
+}
+
+std::string page_header(int type, size_t size, size_t compressed_size, uint64_t num_values, bool dictionary_encoded) {
   Thrift t;
   t.i32(1, type);
   t.i32(2, (int32_t)size);
-  t.i32(3, (int32_t)size);
+  t.i32(3, (int32_t)compressed_size);
   if (type == kDataPage) {
     t.begin_struct(5);
     t.i32(1, (int32_t)num_values);
@@ -82,6 +146,8 @@ std::string page_header(int type, size_t size, uint64_t num_values, bool diction
 
 }  // namespace
 
+bool parquet_writer_uses_snappy() { return snappy_pages(); }
+
 struct ParquetWriter::Impl {
   FILE* f = nullptr;
   std::string path;
@@ -96,6 +162,18 @@ struct ParquetWriter::Impl {
     if (s.empty()) return;
     if (fwrite(s.data(), 1, s.size(), f) != s.size()) throw DxError(DX_E_IO, "write failed: " + path);
     at += s.size();
+  }
+  bool snappy = snappy_pages();
+  std::string packed;
+  // one page: header, then the body as the file's codec wants it; returns the bytes the page would take uncompressed
+  int64_t write_page(int type, const std::string& body, uint64_t num_values, bool dictionary_encoded) {
+    const std::string* out = &body;
+    if (snappy) { snappy_compress(body, packed); out = &packed; }
+    if (out->size() >= (1ull << 31)) throw DxError(DX_E_RANGE, "page of 2 GiB or more in " + path);
+    const std::string h = page_header(type, body.size(), out->size(), num_values, dictionary_encoded);
+    write(h);
+    write(*out);
+    return (int64_t)(h.size() + body.size());
   }
 };
 
@@ -162,13 +240,9 @@ static ChunkMeta write_id_chunk(ParquetWriter::Impl* p, const int64_t* ids, uint
   ChunkMeta m{};
   m.num_values = (int64_t)n;
   m.dict_offset = (int64_t)p->at;
-  const std::string dh = page_header(kDictionaryPage, dict.size(), n_dict, true);
-  p->write(dh);
-  p->write(dict);
+  m.total_uncompressed = p->write_page(kDictionaryPage, dict, n_dict, true);
   m.data_offset = (int64_t)p->at;
-  const std::string ph = page_header(kDataPage, data.size(), n, true);
-  p->write(ph);
-  p->write(data);
+  m.total_uncompressed += p->write_page(kDataPage, data, n, true);
   m.total_size = (int64_t)p->at - m.dict_offset;
   return m;
 }
@@ -182,8 +256,7 @@ static ChunkMeta write_string_chunk(ParquetWriter::Impl* p, const std::string* v
   m.num_values = (int64_t)n;
   m.dict_offset = -1;
   m.data_offset = (int64_t)p->at;
-  p->write(page_header(kDataPage, data.size(), n, false));
-  p->write(data);
+  m.total_uncompressed = p->write_page(kDataPage, data, n, false);
   m.total_size = (int64_t)p->at - m.data_offset;
   return m;
 }
@@ -225,7 +298,7 @@ void ParquetWriter::close() {
     int64_t total = 0;
     for (size_t c = 0; c < g.cols.size(); ++c) {
       const ChunkMeta& m = g.cols[c];
-      total += m.total_size;
+      total += m.total_uncompressed;
       t.elem_struct_begin();  // ColumnChunk
       t.i64(2, m.dict_offset >= 0 ? m.dict_offset : m.data_offset);
       t.begin_struct(3);      // ColumnMetaData
@@ -234,20 +307,20 @@ void ParquetWriter::close() {
       else { t.list(2, 5, 2); t.elem_i32(kPlain); t.elem_i32(kRle); }
       t.list(3, 8, 1);
       t.elem_str(p->names[c]);
-      t.i32(4, kUncompressed);
+      t.i32(4, p->snappy ? kSnappy : kUncompressed);
       t.i64(5, m.num_values);
-      t.i64(6, m.total_size);
+      t.i64(6, m.total_uncompressed);
       t.i64(7, m.total_size);
       t.i64(9, m.data_offset);
       if (m.dict_offset >= 0) t.i64(11, m.dict_offset);
       t.end_struct();
       t.end_struct();
     }
-    t.i64(2, total);
+    t.i64(2, total);  // total_byte_size: the uncompressed bytes of the row group's column data
     t.i64(3, (int64_t)g.rows);
     t.end_struct();
   }
-  t.str(6, "diaeresis-hip (parquet format 1, plain dictionary pages, uncompressed)");
+  t.str(6, p->snappy ? "diaeresis-hip (parquet format 1, plain dictionary pages, snappy)" : "diaeresis-hip (parquet format 1, plain dictionary pages, uncompressed)");
   t.out.push_back(0);
   p->write(t.out);
   std::string tail;

@@ -321,6 +321,7 @@ void read_parquet_strings(const std::string& path, const std::vector<std::string
 
 // dx_parquet.cpp: files of REQUIRED string columns as the reference's Spark jobs write them (schemas of
 // utils/Types.scala:7-16). A column is given as term ids over a string pool, or as strings.
+bool parquet_writer_uses_snappy();  // DX_PARQUET_CODEC=snappy: pages compressed like Spark's own (file names say so too)
 class ParquetWriter {
  public:
   struct Column { const int64_t* ids; const std::string* strings; };

@@ -140,13 +140,17 @@ def test_native_parquet_writer_is_read_back_by_pyarrow(tmp_path):
 
     def term(k):
         return '"h\u00e9llo \U0001F642"@fr' if k == 1 else "<t%d>" % k + "x" * (k % 97)
-    for rows in (0, 1, 9, 3000000):
-        out = str(tmp_path / ("t%d.parquet" % rows))
-        r = subprocess.run([exe, out, str(rows), str(T)], capture_output=True, text=True, timeout=300)
+    for rows, codec in ((0, ""), (1, ""), (9, "snappy"), (3000000, ""), (3000000, "snappy"), (0, "snappy")):
+        out = str(tmp_path / ("t%d%s.parquet" % (rows, codec)))
+        r = subprocess.run([exe, out, str(rows), str(T)], capture_output=True, text=True, timeout=300, env=dict(os.environ, DX_PARQUET_CODEC=codec))
         assert r.returncode == 0, r.stderr
         t = pq.read_table(out)
         assert t.column_names == ["_1", "_2", "parts"] and t.num_rows == rows
         md = pq.ParquetFile(out).metadata
+        if rows:
+            assert md.row_group(0).column(0).compression == ("SNAPPY" if codec else "UNCOMPRESSED")
+        if rows == 3000000 and codec:  # the terms of the test compress well; the bit-packed indices hardly
+            assert os.path.getsize(out) < 0.7 * os.path.getsize(str(tmp_path / "t3000000.parquet"))
         assert md.num_row_groups >= (rows + (1 << 20) - 1) // (1 << 20) and md.num_rows == rows
         a, b, c = t["_1"].to_pylist(), t["_2"].to_pylist(), t["parts"].to_pylist()
         for i in list(range(0, rows, 9973)) + [x for x in (1, rows - 1, (1 << 20) - 1, 1 << 20) if 0 <= x < rows]:
@@ -233,11 +237,12 @@ def test_native_parquet_reader_reads_what_spark_style_writers_write(tmp_path):
            "-I" + os.path.join(root, "include"), "-o", wexe, os.path.join(root, "tests", "native", "parquet_writer_harness.cpp"),
            os.path.join(root, "opus_amd", "csrc", "dx_parquet.cpp")]
     assert subprocess.run(cmd, capture_output=True, text=True, timeout=300).returncode == 0
-    own = str(tmp_path / "own.parquet")
-    assert subprocess.run([wexe, own, "1200000", "5000"], capture_output=True, timeout=300).returncode == 0
-    got, info = _read_with_harness(exe, own, ["_1", "_2", "parts"], tmp_path)
-    t = pq.read_table(own)
-    assert got == [[x.encode() for x in t[c].to_pylist()] for c in ("_1", "_2", "parts")]
+    for codec in ("", "snappy"):
+        own = str(tmp_path / ("own%s.parquet" % codec))
+        assert subprocess.run([wexe, own, "1200000", "5000"], capture_output=True, timeout=300, env=dict(os.environ, DX_PARQUET_CODEC=codec)).returncode == 0
+        got, info = _read_with_harness(exe, own, ["_1", "_2", "parts"], tmp_path)
+        t = pq.read_table(own)
+        assert got == [[x.encode() for x in t[c].to_pylist()] for c in ("_1", "_2", "parts")]
     # refused: a null, a codec that is not read, a column that is not a string, a column that is not there, not a Parquet file
     pq.write_table(pa.table({"_1": ["a", None], "_2": ["b", "c"]}), str(tmp_path / "null.parquet"))
     got, err = _read_with_harness(exe, str(tmp_path / "null.parquet"), ["_1", "_2"], tmp_path)

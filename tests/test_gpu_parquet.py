@@ -47,7 +47,7 @@ def test_export_import_round_trip(tmp_path, lubm1):
         e2.close()
 
 
-def test_native_import_of_a_layout_written_the_way_spark_writes_it(tmp_path, lubm1):
+def test_native_import_of_a_layout_written_the_way_spark_writes_it(tmp_path, lubm1, monkeypatch):
     """The library reads a layout's Parquet files itself (dx_import_layout; dx_open_dataset falls back to it when the
     layout has no id columns beside it): its own files, and the same tables rewritten the way Spark leaves them --
     snappy, nullable columns, several part files per directory, no dx_<N> directory. Counts and bindings equal the
@@ -66,8 +66,21 @@ def test_native_import_of_a_layout_written_the_way_spark_writes_it(tmp_path, lub
     try:
         e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
         e.write_layout(base, "lubm", str(tmp_path / "own"))
+        # the library's writer with Spark's default codec: same layout, the files say so by name, and they are smaller
+        monkeypatch.setenv("DX_PARQUET_CODEC", "snappy")
+        os.makedirs(str(tmp_path / "own_snappy"))
+        e.write_layout(str(tmp_path / "own_snappy") + "/", "lubm", str(tmp_path / "own_snappy"))
+        monkeypatch.delenv("DX_PARQUET_CODEC")
     finally:
         e.close()
+    from parity_util import assert_layout_equals_oracle
+    assert_layout_equals_oracle(str(tmp_path / "own_snappy") + "/", "lubm", 4, str(tmp_path / "own_snappy"), ref)
+
+    def parquet_bytes(root):
+        return sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(os.path.join(root, "lubm_data", "cluster")) for f in fs if f.endswith(".parquet"))
+    names = [f for _, _, fs in os.walk(str(tmp_path / "own_snappy" / "lubm_data" / "cluster")) for f in fs if f.endswith(".parquet")]
+    assert names and all(f.endswith(".snappy.parquet") for f in names)
+    assert parquet_bytes(str(tmp_path / "own_snappy")) < 0.8 * parquet_bytes(str(tmp_path / "own"))
     # the same layout as Spark would have left it
     spark = str(tmp_path / "spark") + "/"
     src_root, dst_root = P.cluster_dir(base, "lubm", 4), P.cluster_dir(spark, "lubm", 4)
@@ -90,11 +103,11 @@ def test_native_import_of_a_layout_written_the_way_spark_writes_it(tmp_path, lub
     for u, c in ref["node_index"]:
         ni.setdefault(u, []).append(c)
     cidx = T.load_class_index(lubm1["class_index"])
-    for how in ("own files, dx_import_layout", "spark files, dx_open_dataset"):
+    for how in ("own files, dx_import_layout", "own snappy files, dx_import_layout", "spark files, dx_open_dataset"):
         e2 = Engine(0)
         try:
             if how.startswith("own"):
-                tables, rows = e2.import_layout(base, "lubm", 4)
+                tables, rows = e2.import_layout(str(tmp_path / "own_snappy") + "/" if "snappy" in how else base, "lubm", 4)
                 assert (tables, rows) == (len(ref["vp"]), n_rows)
             else:
                 e2.open_dataset(spark, "lubm", 4)
