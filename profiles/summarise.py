@@ -51,7 +51,7 @@ def main(tag, stats_dir, fetch_dir, write_dir):
                       "read_bytes": fk * 1024 * 2, "write_bytes": wk * 1024, "bytes": fk * 1024 * 2 + wk * 1024}
     json.dump(traffic, open(os.path.join(HERE, tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     with open(os.path.join(HERE, tag + "_summary.md"), "w") as f:
-        f.write("# %s: rocprofv3 summaries (MI355X, LUBM-100, `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`)\n\n" % tag)
+        f.write("# %s: rocprofv3 summaries (MI355X, LUBM-100, `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-file-leg`, see `collect.sh`)\n\n" % tag)
         f.write("Kernel trace (`rocprofv3 --kernel-trace --stats`; 7 partition calls = 1 sizing + 1 warm-up + 5 timed; "
                 "full CSV in `%s_kernel_stats.csv`). HBM traffic per launch from separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
                 "runs of the same command with `--steps 2` (KiB as the counters report them; `read GB` doubles FETCH_SIZE, see "
