@@ -472,7 +472,7 @@ void read_parquet_strings(const std::string& path, const std::vector<std::string
           if (h.num_nulls) bad(path, "null in column " + columns[c] + " (the tables of the layout hold none)");
           const uint8_t* b = body + h.def_bytes;  // levels are never compressed in a page of the second version
           const int32_t data_c = h.compressed - h.def_bytes, data_u = h.uncompressed - h.def_bytes;
-          if (data_c < 0 || data_u < 0) bad(path, "definition levels longer than their page");
+          if (h.def_bytes < 0 || data_c < 0 || data_u < 0) bad(path, "definition levels longer than their page");
           const uint8_t* e = b + data_c;
           if (ch.codec == kSnappy && h.v2_compressed) {
             snappy_uncompress(b, data_c, page, data_u, path);
