@@ -1394,6 +1394,13 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
             uint32_t* __restrict__ block_s /*[block]: 's' entries of the block's 1024 rows*/, uint32_t* __restrict__ block_o) {
   // four consecutive rows per lane: 16- and 32-byte loads, one 4-byte store per output instead of four 1-byte ones
   __shared__ uint32_t lds[8];
+  // 'o' entries repeat at short range (the students of a department follow one another and share its courses): a
+  // block keeps one of each (partition, predicate, object) among its 1024 rows, whichever row enters this set
+  // first, and the sort that makes the entries distinct has that much less to carry.
+  constexpr uint32_t kSeen = 2048;  // at most half full
+  __shared__ unsigned long long seen[kSeen];
+  for (uint32_t j = threadIdx.x; j < kSeen; j += 256) seen[j] = ~0ull;
+  __syncthreads();
   const uint32_t total = part_base[nparts];
   const uint32_t i0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
   uint32_t es4 = 0, eo4 = 0;
@@ -1434,6 +1441,14 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
         if (!class_used[o[k]]) class_used[o[k]] = 1;
       } else {
         eo = (flags[o[k]] & kFlagNode) != 0;
+        if (eo) {
+          const unsigned long long key = ((unsigned long long)q << 58) | ((unsigned long long)p[k] << 32) | o[k];
+          for (uint32_t at = (uint32_t)(mix64(key) >> 40) & (kSeen - 1);; at = (at + 1) & (kSeen - 1)) {
+            const unsigned long long was = atomicCAS(&seen[at], ~0ull, key);
+            if (was == ~0ull) break;
+            if (was == key) { eo = false; break; }
+          }
+        }
       }
       es4 |= (uint32_t)es << (8 * k);
       eo4 |= (uint32_t)eo << (8 * k);
@@ -1816,14 +1831,19 @@ __global__ void __launch_bounds__(1024) k_sum_u32(const uint32_t* __restrict__ i
   if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += lds[w]; *out = t; }
 }
 
+// *out += the sum of in[0, n): each block adds up a slice and contributes it with one atomic (*out starts at zero)
 __global__ void __launch_bounds__(1024) k_sum_u32_u64(const uint32_t* __restrict__ in, uint32_t n, unsigned long long* __restrict__ out) {
   __shared__ unsigned long long lds[16];
   unsigned long long v = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) v += in[i];
+  for (uint32_t i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) v += in[i];
   v = wave_reduce_u64(v);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < 16; ++w) t += lds[w]; *out = t; }
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 16; ++w) t += lds[w];
+    if (t) atomicAdd(out, t);
+  }
 }
 
 __global__ void k_pick_strided(const uint32_t* __restrict__ in, size_t stride, int n, uint32_t* __restrict__ out) {
@@ -2376,8 +2396,8 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     if (n_rec) exclusive_scan_u32_u32(pool, tile_firsts.p, tile_firsts.p, (size_t)ntiles + 1, d_total.p, s);
     else DX_HIP(hipMemsetAsync(d_total.p, 0, 4, s));
     if (n_rec) hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(1024), 0, s, tile_leaders.p, ntiles, d_total.p + 1);
-    if (n_rec) hipLaunchKernelGGL(k_sum_u32_u64, dim3(1), dim3(1024), 0, s, tile_bytes.p, ntiles, d_pool_bytes.p);
-    else DX_HIP(hipMemsetAsync(d_pool_bytes.p, 0, 8, s));
+    DX_HIP(hipMemsetAsync(d_pool_bytes.p, 0, 8, s));
+    if (n_rec) hipLaunchKernelGGL(k_sum_u32_u64, dim3(std::min(blocks(ntiles, 1024), 64u)), dim3(1024), 0, s, tile_bytes.p, ntiles, d_pool_bytes.p);
     fetch.add(&pool_bytes, d_pool_bytes.p, 8);
     unsigned long long h_err = ~0ull;
     uint32_t h_coll[2] = {0, 0};
@@ -2544,7 +2564,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     DevBuf<unsigned long long> d_nv(pool, 1);
     DX_HIP(hipMemsetAsync(d_nv.p, 0, 8, s));
     if (n_terms)
-      hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 256u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
+      hipLaunchKernelGGL(k_list_preds, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, is_pred, pred_index.p, ps.term_flags.p, n_terms, d_preds.p, d_nv.p);
     const uint32_t at_once = (uint32_t)std::min<uint64_t>(kPredsAtOnce, n_terms);
     std::vector<uint32_t> hp(at_once);
     unsigned long long nv = 0;
