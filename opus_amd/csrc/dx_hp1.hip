@@ -1198,35 +1198,60 @@ k_place(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pid
         uint64_t* __restrict__ mask, uint8_t* __restrict__ node_flag, unsigned long long* __restrict__ counters /*0 uniq, 1 edges, 2 rows over all partitions*/) {
   // Grid-stride: the counters are hit once per block at the end, and the grid is about a thousand blocks.
   // (Atomics of many blocks on one word are served one after another by a single L2 channel.)
+  // A triple's mask hangs on three loads one after another (key, term flags, vertex masks), so a thread works on
+  // four triples at a time and has the four chains in flight together; every load is predicated, none sits in a branch.
   uint32_t uq = 0, ed = 0;
   uint64_t rows = 0;  // a triple is one row in each of its partitions: the split's 32-bit positions must hold the sum
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const K k = keys[i];
-    uint64_t m = 0;
-    uint8_t nf = 0;
-    if (i == 0 || keys[i - 1] != k) {
-      const Unpacked t = unpack(k, bits_term);
-      if (t.pidx == type_pidx) {
-        m = (flags[t.s] & kFlagEdge) ? Pm[t.o] : 0;
-        nf = m != 0;
-      } else if (flags[t.o] & kFlagLiteral) {
-        m = (flags[t.s] & kFlagEdge) ? M[t.s] : 0;
-      } else {
-        m = M[t.s] | M[t.o];
-      }
-      // With several ranks a triple reaches every owner of one of its partitions: the owner of the lowest
-      // one counts it and keeps its node-index row (one GPU: owned = all ones, so always).
-      const bool mine = m == 0 ? owned == ~0ull : ((m & (~m + 1)) & owned) != 0;
-      if (mine) {
-        ++uq;
-        if (t.pidx != type_pidx && !(flags[t.o] & kFlagLiteral)) ++ed;
-      }
-      nf = nf && mine;
-      m &= owned;
+  const uint64_t stride = (uint64_t)gridDim.x * 1024;
+  for (uint64_t b = (uint64_t)blockIdx.x * 1024 + threadIdx.x; b < n; b += stride) {
+    K k[4], kp[4];
+    bool fresh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t i = b + 256 * j;
+      const bool in = i < n;
+      k[j] = in ? keys[i] : K{};
+      kp[j] = (in && i) ? keys[i - 1] : K{};
+      fresh[j] = in && (i == 0 || kp[j] != k[j]);
     }
-    mask[i] = m;
-    node_flag[i] = nf;
-    rows += (uint64_t)__popcll(m);
+    Unpacked t[4];
+    uint8_t fs[4], fo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[j] = unpack(k[j], bits_term);
+      fs[j] = fresh[j] ? flags[t[j].s] : 0;
+      fo[j] = fresh[j] ? flags[t[j].o] : 0;
+    }
+    uint64_t pm[4], ms[4], mo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool is_type = t[j].pidx == type_pidx, lit = (fo[j] & kFlagLiteral) != 0, edge = (fs[j] & kFlagEdge) != 0;
+      pm[j] = (fresh[j] && is_type && edge) ? Pm[t[j].o] : 0;
+      ms[j] = (fresh[j] && !is_type && (!lit || edge)) ? M[t[j].s] : 0;
+      mo[j] = (fresh[j] && !is_type && !lit) ? M[t[j].o] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t i = b + 256 * j;
+      if (i >= n) continue;
+      const bool is_type = t[j].pidx == type_pidx;
+      uint64_t m = is_type ? pm[j] : (ms[j] | mo[j]);
+      bool nf = is_type && m != 0;
+      if (fresh[j]) {
+        // With several ranks a triple reaches every owner of one of its partitions: the owner of the lowest
+        // one counts it and keeps its node-index row (one GPU: owned = all ones, so always).
+        const bool mine = m == 0 ? owned == ~0ull : ((m & (~m + 1)) & owned) != 0;
+        if (mine) {
+          ++uq;
+          if (!is_type && !(fo[j] & kFlagLiteral)) ++ed;
+        }
+        nf = nf && mine;
+        m &= owned;
+      }
+      mask[i] = m;
+      node_flag[i] = nf ? 1 : 0;
+      rows += (uint64_t)__popcll(m);
+    }
   }
   __shared__ uint32_t lds[8];
   uint32_t tu, te;
