@@ -1416,7 +1416,8 @@ __global__ void __launch_bounds__(256)
 k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o, const uint32_t* __restrict__ row_p,
             const uint32_t* __restrict__ part_base, int nparts, uint32_t type_pidx, const uint8_t* __restrict__ flags,
             uint8_t* __restrict__ es_out, uint8_t* __restrict__ eo_out, uint8_t* __restrict__ class_used,
-            uint32_t* __restrict__ block_s /*[block]: 's' entries of the block's 1024 rows*/, uint32_t* __restrict__ block_o) {
+            uint32_t* __restrict__ block_s /*[block]: 's' entries of the block's 1024 rows*/, uint32_t* __restrict__ block_o,
+            int drop_repeats /*partition, predicate index and object fit the set's 64-bit word: 6 + 26 + 32 bits*/) {
   // four consecutive rows per lane: 16- and 32-byte loads, one 4-byte store per output instead of four 1-byte ones
   __shared__ uint32_t lds[8];
   // 'o' entries repeat at short range (the students of a department follow one another and share its courses): a
@@ -1466,7 +1467,7 @@ k_vpi_flags(const int64_t* __restrict__ row_s, const int64_t* __restrict__ row_o
         if (!class_used[o[k]]) class_used[o[k]] = 1;
       } else {
         eo = (flags[o[k]] & kFlagNode) != 0;
-        if (eo) {
+        if (eo && drop_repeats) {
           const unsigned long long key = ((unsigned long long)q << 58) | ((unsigned long long)p[k] << 32) | o[k];
           for (uint32_t at = (uint32_t)(mix64(key) >> 40) & (kSeen - 1);; at = (at + 1) & (kSeen - 1)) {
             const unsigned long long was = atomicCAS(&seen[at], ~0ull, key);
@@ -2792,7 +2793,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
     DX_HIP(hipMemsetAsync(class_used.p, 0, class_used.bytes(), s));
     DX_HIP(hipMemsetAsync(n_type_ent.p, 0, 16, s));
     hipLaunchKernelGGL(k_vpi_flags, dim3(vpi_blocks), dim3(256), 0, s, ps.row_s.p, ps.row_o.p, ps.row_p.p, d_part_base.p, nparts,
-                       ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p, block_s.p, block_o.p);
+                       ps.type_pidx, ps.term_flags.p, es.p, eo.p, class_used.p, block_s.p, block_o.p, bits_pred <= 26 ? 1 : 0);
     exclusive_scan_u32_u32(pool, block_s.p, block_s.p, vpi_blocks, totals.p, s);
     exclusive_scan_u32_u32(pool, block_o.p, block_o.p, vpi_blocks, totals.p + 1, s);
     hipLaunchKernelGGL(k_vpi_type_entries<uint64_t>, dim3(std::min(blocks(n_terms), 1024u)), dim3(256), 0, s, class_used.p, Pm.p, owned, n_terms, ps.type_pidx,
