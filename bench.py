@@ -147,12 +147,20 @@ def file_leg(eng, arr, text, n_bytes, class_index, n_partitions):
         t0 = time.perf_counter()
         eng.write_layout(os.path.join(d, "store"), "bench", d)
         t_layout = time.perf_counter() - t0
+        lt = eng.layout_times()
         size = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(os.path.join(d, "store")) for f in fs)
         return {"partition_file_ms": t_file * 1e3, "of_which_device_ms": st.ms_total,
                 "file_GBps": n_bytes / t_file / 1e9,
                 "write_layout_ms": t_layout * 1e3, "layout_bytes": size,
-                "note": "file in the page cache -> pinned staging (2 x 64 MiB, read and upload overlapped) -> HBM -> partitions; "
-                        "then Parquet (dictionary pages, uncompressed) + id columns + text files on local disk, the files encoded and written by up to 16 host threads"}
+                "write_layout_legs_ms": {"directories_and_text_files": lt["prepare_ms"], "device_encode": lt["encode_ms"],
+                                         "device_to_host": lt["d2h_ms"], "file_write_first_to_last": lt["write_wall_ms"],
+                                         "file_write_summed_over_threads": lt["write_busy_ms"], "threads": lt["threads"]},
+                "file_write_GBps": lt["bytes"] / max(lt["write_wall_ms"], 1e-6) / 1e6,
+                "end_to_end_triples_per_s": st.n_triples / (t_file + t_layout),
+                "note": "file in the page cache -> pinned staging (read and upload overlapped) -> HBM -> partitions; then the "
+                        "reference's layout on local disk: Parquet pages (dictionary pages, uncompressed) encoded on the GPU, the "
+                        "files' bytes copied to pinned host memory piece by piece while host threads write the pieces that have "
+                        "landed (device_to_host and file_write overlap); end_to_end = triples / (partition_file + write_layout)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -155,6 +155,11 @@ int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const 
  * tools never list), the dictionary and the tables' id columns for dx_open_dataset / dx_load_table.
  * DX_E_INVAL if the clusters directory exists (the reference skips the stage then, DAP.scala:86). */
 int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
+/* Where the time of the last dx_part_write_layout went, in the order: whole call, directories and text files, page
+ * encoding on the GPU, the files' bytes coming to pinned host memory, first write started .. last write done, time summed
+ * over the writing threads (all in ms), bytes written, writing threads. Fills min(n, 8) values. The reference only has
+ * its one stage timer for this (DAP.scala:73, 96-97). */
+int dx_layout_times(dx_ctx* ctx, double* out, int n);
 
 /* ---- query processor ------------------------------------------------------------------------------ */
 /* Points the context at a layout (replaces the path arithmetic of QueryProcessor.loadDataset,

@@ -1,6 +1,8 @@
 // C ABI of libdiaeresis_hip.so: context, accessors, on-disk layout, query entry points.
 #include <dirent.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
@@ -8,6 +10,7 @@
 #include <fstream>
 #include <map>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -116,6 +119,7 @@ std::string read_file(const std::string& path) {
   return ss.str();
 }
 
+}  // namespace
 void mkdirs(const std::string& path) {
   std::string cur;
   for (size_t i = 0; i < path.size(); ++i) {
@@ -127,6 +131,7 @@ void mkdirs(const std::string& path) {
   }
 }
 
+namespace {
 struct ColHeader {
   char magic[8];
   uint64_t rows;
@@ -145,6 +150,7 @@ void write_cols(const std::string& path, uint64_t rows, const std::vector<const 
   for (auto* c : host_cols) f.write((const char*)c, (std::streamsize)(rows * 8));
   if (!f) throw DxError(DX_E_IO, "write failed: " + path);
 }
+}  // namespace
 void touch(const std::string& path) { std::ofstream f(path, std::ios::trunc); }
 
 std::string part_name(int i) {
@@ -157,6 +163,7 @@ std::string norm_base(const char* base) {
   if (!b.empty() && b.back() != '/') b += '/';  // DAP.scala:67-68
   return b;
 }
+namespace {
 std::string view_name(const std::string& key) {  // QueryProcessor.scala:216
   std::string v = "table";
   for (char c : key) {
@@ -255,7 +262,7 @@ void dx_free(dx_ctx* ctx) {
   if (ctx->q_ev0) { (void)hipEventDestroy(ctx->q_ev0); (void)hipEventDestroy(ctx->q_ev1); }
   if (ctx->q_host) (void)hipHostFree(ctx->q_host);
   if (ctx->q_counters) (void)hipFree(ctx->q_counters);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < kFileStages; ++b) {
     if (ctx->file_stage[b]) (void)hipHostFree(ctx->file_stage[b]);
     if (ctx->file_stage_ev[b]) (void)hipEventDestroy(ctx->file_stage_ev[b]);
   }
@@ -286,32 +293,91 @@ int dx_partition_file(dx_ctx* ctx, const char* instances_path, const char* class
   return guard(ctx, [&] {
     if (!instances_path) throw DxError(DX_E_INVAL, "null path");
     const std::string ci = class_index_path ? read_file(class_index_path) : std::string();
-    std::ifstream f(instances_path, std::ios::binary | std::ios::ate);
-    if (!f) throw DxError(DX_E_NOENT, std::string("cannot open ") + instances_path);
-    const uint64_t n = (uint64_t)f.tellg();
-    f.seekg(0);
+    const int fd = open(instances_path, O_RDONLY);
+    if (fd < 0) throw DxError(DX_E_NOENT, std::string("cannot open ") + instances_path);
+    struct FdGuard { int fd; ~FdGuard() { close(fd); } } fd_guard{fd};
+    struct stat st;
+    if (fstat(fd, &st) != 0) throw DxError(DX_E_IO, std::string("cannot stat ") + instances_path);
+    const uint64_t n = (uint64_t)st.st_size;
     DevBuf<uint8_t> text(ctx->pool, n + 16);
-    // Streamed through two pinned staging buffers (kept by the context): the file never has to fit in host memory,
-    // and while one buffer's copy to the device is in flight the next piece of the file is read into the other.
-    const size_t chunk = 64u << 20;
-    for (int b = 0; b < 2; ++b) {
+    // Streamed through pinned staging buffers (kept by the context), so the file never has to fit in host memory.
+    // Several threads read: one thread's read() from the page cache runs at about 20 GB/s, less than half of what the
+    // link to the device takes. Piece i goes through buffer i % kFileStages; its reader waits for the upload of the
+    // piece that used the buffer before, this thread queues the uploads in file order.
+    const size_t chunk = 32u << 20;
+    for (int b = 0; b < kFileStages; ++b) {
       if (!ctx->file_stage[b]) DX_HIP(hipHostMalloc(&ctx->file_stage[b], chunk, hipHostMallocDefault));
       if (!ctx->file_stage_ev[b]) DX_HIP(hipEventCreateWithFlags(&ctx->file_stage_ev[b], hipEventDisableTiming));
     }
-    bool in_flight[2] = {false, false};
-    int b = 0;
-    for (uint64_t done = 0; done < n; b ^= 1) {
-      const size_t want = (size_t)std::min<uint64_t>(chunk, n - done);
-      if (in_flight[b]) { DX_HIP(hipEventSynchronize(ctx->file_stage_ev[b])); in_flight[b] = false; }
-      f.read((char*)ctx->file_stage[b], (std::streamsize)want);
-      if ((size_t)f.gcount() != want) {
-        (void)hipStreamSynchronize(ctx->stream);  // the other buffer's copy may still be running
-        throw DxError(DX_E_IO, std::string("short read on ") + instances_path);
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    unsigned n_readers = (unsigned)std::min<uint64_t>(std::min<unsigned>(kFileStages, std::max(1u, std::thread::hardware_concurrency())), std::max<uint64_t>(n_chunks, 1));
+    if (const char* e = getenv("DX_READ_THREADS")) n_readers = (unsigned)std::max(1, std::min(atoi(e), kFileStages));
+    std::vector<int> state(n_chunks, 0);  // 1: read into its buffer, 2: its upload is queued, -1: failed
+    std::mutex mu;
+    std::condition_variable cv;
+    bool give_up = false;
+    const int device = ctx->device;
+    auto reader = [&](unsigned t) {
+      (void)hipSetDevice(device);
+      for (uint64_t i = t; i < n_chunks; i += n_readers) {
+        const int b = (int)(i % kFileStages);
+        if (i >= (uint64_t)kFileStages) {
+          std::unique_lock<std::mutex> l(mu);
+          cv.wait(l, [&] { return give_up || state[i - kFileStages] == 2; });
+          if (give_up) return;
+          l.unlock();
+          if (hipEventSynchronize(ctx->file_stage_ev[b]) != hipSuccess) {
+            std::lock_guard<std::mutex> g(mu);
+            state[i] = -1;
+            cv.notify_all();
+            return;
+          }
+        }
+        const uint64_t at = i * chunk, want = std::min<uint64_t>(chunk, n - at);
+        uint64_t got = 0;
+        while (got < want) {
+          const ssize_t r = pread(fd, (char*)ctx->file_stage[b] + got, want - got, (off_t)(at + got));
+          if (r < 0 && errno == EINTR) continue;
+          if (r <= 0) break;
+          got += (uint64_t)r;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        state[i] = got == want ? 1 : -1;
+        cv.notify_all();
+        if (got != want) return;
       }
-      DX_HIP(hipMemcpyAsync(text.p + done, ctx->file_stage[b], want, hipMemcpyHostToDevice, ctx->stream));
-      DX_HIP(hipEventRecord(ctx->file_stage_ev[b], ctx->stream));
-      in_flight[b] = true;
-      done += want;
+    };
+    std::vector<std::thread> readers;
+    for (unsigned t = 0; t < n_readers; ++t) readers.emplace_back(reader, t);
+    bool failed = false;
+    try {
+      for (uint64_t i = 0; i < n_chunks && !failed; ++i) {
+        {
+          std::unique_lock<std::mutex> l(mu);
+          cv.wait(l, [&] { return state[i] != 0; });
+          if (state[i] < 0) { failed = true; break; }
+        }
+        const int b = (int)(i % kFileStages);
+        const uint64_t at = i * chunk, want = std::min<uint64_t>(chunk, n - at);
+        DX_HIP(hipMemcpyAsync(text.p + at, ctx->file_stage[b], want, hipMemcpyHostToDevice, ctx->stream));
+        DX_HIP(hipEventRecord(ctx->file_stage_ev[b], ctx->stream));
+        std::lock_guard<std::mutex> g(mu);
+        state[i] = 2;
+        cv.notify_all();
+      }
+    } catch (...) {
+      { std::lock_guard<std::mutex> g(mu); give_up = true; }
+      cv.notify_all();
+      for (auto& t : readers) t.join();
+      (void)hipStreamSynchronize(ctx->stream);
+      throw;
+    }
+    { std::lock_guard<std::mutex> g(mu); give_up = true; }
+    cv.notify_all();
+    for (auto& t : readers) t.join();
+    if (failed) {
+      (void)hipStreamSynchronize(ctx->stream);  // uploads of earlier pieces may still be running
+      throw DxError(DX_E_IO, std::string("short read on ") + instances_path);
     }
     DX_HIP(hipStreamSynchronize(ctx->stream));
     const auto classes = parse_class_index(ci, n_partitions);
@@ -610,8 +676,10 @@ int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const 
 }
 
 // ---- on-disk layout -----------------------------------------------------------------------------------
-int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
-  return guard(ctx, [&] {
+// The layout with the files encoded by host threads: taken when snappy pages are asked for (DX_PARQUET_CODEC=snappy),
+// which the GPU encoder does not make.
+static void write_layout_host(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
+  {
     const PartitionState& ps = ctx->part;
     const Dictionary& d = ctx->dict;
     if (!ps.valid || !dataset) throw DxError(DX_E_INVAL, "no partition run / null dataset");
@@ -650,6 +718,7 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
     // The files are independent of each other: this thread fetches each file's id columns from the device and makes
     // the directories, a pool of host threads encodes and writes (one thread took 6.1 s for LUBM-100's 5.6 GB).
     std::vector<std::pair<uint64_t, std::function<void()>>> jobs;  // (values, work)
+    std::vector<std::string> success;  // the markers are written when the files are
     // the ids of the files that wait for a thread are held in host memory: at 2^28 values (2 GiB) the pool runs what there is
     auto flush_if_large = [&] {
       uint64_t held = 0;
@@ -687,7 +756,7 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
       const std::string qs = std::to_string(q);
       stats << (qs.size() == 1 ? "0" + qs : qs) << " " << n << "\n";
     }
-    touch(clusters + "/_SUCCESS");
+    success.push_back(clusters + "/_SUCCESS");
     // VP directories (DAP.scala:419-437) and partition_stat (DAP.scala:101-114)
     std::map<std::string, uint64_t> dir_rows;
     std::map<std::string, int> file_no;
@@ -710,7 +779,7 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
       });
       flush_if_large();
       dir_rows[part_name(t.partition)] += t.rows;
-      touch(pdir + "/_SUCCESS");
+      success.push_back(pdir + "/_SUCCESS");
     }
     {
       std::ofstream pstat(L + D + "_local/partition_stat.txt_" + N + "_bal");
@@ -740,7 +809,7 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
         w.append(n, {{hs->data(), nullptr}, {ho->data(), nullptr}}, pool_p, off_p, nt);
         w.close();
       });
-      touch(ni + "/_SUCCESS");
+      success.push_back(ni + "/_SUCCESS");
     }
     // VP index (DAP.scala:450-501): one row per uri with the set of "s" / "o" + sanitised predicate it occurs with,
     // joined by commas (collect_set leaves the order open: sorted here)
@@ -787,9 +856,26 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
       w.append(uris.size(), {{uris.data(), nullptr}, {nullptr, parts.data()}}, pool_p, off_p, nt);
       w.close();
       });
-      touch(dir + "/_SUCCESS");
+      success.push_back(dir + "/_SUCCESS");
     }
     run_jobs(jobs);
+    for (const std::string& p : success) touch(p);
+  }
+}
+
+int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
+  return guard(ctx, [&] {
+    if (parquet_writer_uses_snappy()) write_layout_host(ctx, base, dataset, local_dir);
+    else write_layout(ctx, base, dataset, local_dir);
+  });
+}
+
+int dx_layout_times(dx_ctx* ctx, double* out, int n) {
+  return guard(ctx, [&] {
+    if (!out || n < 0) throw DxError(DX_E_INVAL, "null output");
+    const LayoutTimes& t = ctx->layout_times;
+    const double v[8] = {t.total_ms, t.prepare_ms, t.encode_ms, t.d2h_ms, t.write_wall_ms, t.write_busy_ms, (double)t.bytes, (double)t.threads};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   });
 }
 

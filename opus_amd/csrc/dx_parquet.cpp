@@ -53,7 +53,7 @@ struct Thrift {
 
 constexpr int kByteArray = 6, kRequired = 0, kUtf8 = 0, kPlain = 0, kPlainDictionary = 2, kRle = 3, kUncompressed = 0, kSnappy = 1;
 constexpr int kDataPage = 0, kDictionaryPage = 2;
-constexpr uint64_t kRowGroupRows = 1u << 20;
+constexpr uint64_t kRowGroupRows = kParquetRowGroupRows;
 
 struct ChunkMeta {
   int64_t dict_offset, data_offset, total_size, total_uncompressed, num_values;
@@ -274,15 +274,17 @@ void ParquetWriter::append(uint64_t n, const std::vector<Column>& cols, const ui
   p->rows += n;
 }
 
-void ParquetWriter::close() {
+// The file's footer: FileMetaData in the compact protocol, its length, the magic.
+struct FooterGroup { uint64_t rows; std::vector<ChunkMeta> cols; };
+static std::string footer_bytes(const std::vector<std::string>& names, uint64_t rows, const std::vector<FooterGroup>& groups, bool snappy) {
   Thrift t;
   t.i32(1, 1);  // version
-  t.list(2, 12, p->names.size() + 1);
+  t.list(2, 12, names.size() + 1);
   t.elem_struct_begin();  // root
   t.str(4, "spark_schema");
-  t.i32(5, (int32_t)p->names.size());
+  t.i32(5, (int32_t)names.size());
   t.end_struct();
-  for (const std::string& nm : p->names) {
+  for (const std::string& nm : names) {
     t.elem_struct_begin();
     t.i32(1, kByteArray);
     t.i32(3, kRequired);
@@ -290,9 +292,9 @@ void ParquetWriter::close() {
     t.i32(6, kUtf8);
     t.end_struct();
   }
-  t.i64(3, (int64_t)p->rows);
-  t.list(4, 12, p->groups.size());
-  for (const auto& g : p->groups) {
+  t.i64(3, (int64_t)rows);
+  t.list(4, 12, groups.size());
+  for (const auto& g : groups) {
     t.elem_struct_begin();
     t.list(1, 12, g.cols.size());
     int64_t total = 0;
@@ -306,8 +308,8 @@ void ParquetWriter::close() {
       if (m.dict_offset >= 0) { t.list(2, 5, 2); t.elem_i32(kPlainDictionary); t.elem_i32(kRle); }
       else { t.list(2, 5, 2); t.elem_i32(kPlain); t.elem_i32(kRle); }
       t.list(3, 8, 1);
-      t.elem_str(p->names[c]);
-      t.i32(4, p->snappy ? kSnappy : kUncompressed);
+      t.elem_str(names[c]);
+      t.i32(4, snappy ? kSnappy : kUncompressed);
       t.i64(5, m.num_values);
       t.i64(6, m.total_uncompressed);
       t.i64(7, m.total_size);
@@ -320,15 +322,94 @@ void ParquetWriter::close() {
     t.i64(3, (int64_t)g.rows);
     t.end_struct();
   }
-  t.str(6, p->snappy ? "diaeresis-hip (parquet format 1, plain dictionary pages, snappy)" : "diaeresis-hip (parquet format 1, plain dictionary pages, uncompressed)");
+  t.str(6, snappy ? "diaeresis-hip (parquet format 1, plain dictionary pages, snappy)" : "diaeresis-hip (parquet format 1, plain dictionary pages, uncompressed)");
   t.out.push_back(0);
-  p->write(t.out);
-  std::string tail;
-  put_u32(tail, (uint32_t)t.out.size());
-  tail += "PAR1";
-  p->write(tail);
+  std::string out = t.out;
+  put_u32(out, (uint32_t)t.out.size());
+  out += "PAR1";
+  return out;
+}
+
+void ParquetWriter::close() {
+  std::vector<FooterGroup> groups;
+  for (auto& g : p->groups) groups.push_back({g.rows, g.cols});
+  p->write(footer_bytes(p->names, p->rows, groups, p->snappy));
   if (fclose(p->f) != 0) { p->f = nullptr; throw DxError(DX_E_IO, "close failed: " + p->path); }
   p->f = nullptr;
+}
+
+// ---- a file whose page bodies are made elsewhere ---------------------------------------------------------------
+// The same file format as ParquetWriter's, uncompressed, for a caller that has the page bodies encoded on the GPU: from
+// the sizes of every column chunk's pages this lays the file out, writes everything that is not a page body (magic, page
+// headers, the bit width and run header in front of the packed indices, footer) and says where each body belongs.
+PqFilePlan plan_parquet_file(const std::vector<std::string>& names, const std::vector<uint64_t>& group_rows, const std::vector<PqChunkIn>& chunks) {
+  if (chunks.size() != names.size() * group_rows.size()) throw DxError(DX_E_INVAL, "parquet plan: chunk count differs from row groups x columns");
+  PqFilePlan plan;
+  plan.chunks.resize(chunks.size());
+  uint64_t at = 0, cur_at = 0;
+  std::string cur;
+  auto host = [&](const std::string& b) { if (cur.empty()) cur_at = at; cur += b; at += b.size(); };
+  auto device = [&](uint64_t bytes) {
+    if (!cur.empty()) { plan.host.emplace_back(cur_at, std::move(cur)); cur.clear(); }
+    const uint64_t here = at;
+    at += bytes;
+    return here;
+  };
+  host("PAR1");
+  std::vector<FooterGroup> groups;
+  uint64_t rows = 0;
+  size_t k = 0;
+  for (uint64_t gr : group_rows) {
+    FooterGroup g;
+    g.rows = gr;
+    rows += gr;
+    for (size_t c = 0; c < names.size(); ++c, ++k) {
+      const PqChunkIn& in = chunks[k];
+      PqChunkOut& out = plan.chunks[k];
+      ChunkMeta m{};
+      m.num_values = (int64_t)in.num_values;
+      if (in.plain) {
+        if (in.plain_bytes >= (1ull << 31)) throw DxError(DX_E_RANGE, "data page of 2 GiB or more");
+        m.dict_offset = -1;
+        m.data_offset = (int64_t)at;
+        const std::string h = page_header(kDataPage, in.plain_bytes, in.plain_bytes, in.num_values, false);
+        host(h);
+        out.data_at = device(in.plain_bytes);
+        out.data_bytes = in.plain_bytes;
+        m.total_uncompressed = (int64_t)(h.size() + in.plain_bytes);
+        m.total_size = (int64_t)at - m.data_offset;
+      } else {
+        if (in.dict_bytes >= (1ull << 31)) throw DxError(DX_E_RANGE, "dictionary page of 2 GiB or more");
+        int width = 0;
+        while ((1ull << width) < in.n_dict) ++width;
+        const uint64_t n8 = (in.num_values + 7) / 8;
+        std::string prefix;  // bit width, then the header of one bit-packed run of n8 groups of eight values
+        prefix.push_back((char)width);
+        { Thrift v; v.varint((n8 << 1) | 1); prefix += v.out; }
+        const uint64_t body = prefix.size() + n8 * (uint64_t)width;
+        if (body >= (1ull << 31)) throw DxError(DX_E_RANGE, "data page of 2 GiB or more");
+        m.dict_offset = (int64_t)at;
+        const std::string hd = page_header(kDictionaryPage, in.dict_bytes, in.dict_bytes, in.n_dict, true);
+        host(hd);
+        out.dict_at = device(in.dict_bytes);
+        m.data_offset = (int64_t)at;
+        const std::string hp = page_header(kDataPage, body, body, in.num_values, true);
+        host(hp);
+        host(prefix);
+        out.width = (uint32_t)width;
+        out.data_bytes = n8 * (uint64_t)width;
+        out.data_at = device(out.data_bytes);
+        m.total_uncompressed = (int64_t)(hd.size() + in.dict_bytes + hp.size() + body);
+        m.total_size = (int64_t)at - m.dict_offset;
+      }
+      g.cols.push_back(m);
+    }
+    groups.push_back(std::move(g));
+  }
+  host(footer_bytes(names, rows, groups, false));
+  if (!cur.empty()) plan.host.emplace_back(cur_at, std::move(cur));
+  plan.size = at;
+  return plan;
 }
 
 }  // namespace dx

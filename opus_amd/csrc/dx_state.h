@@ -89,6 +89,20 @@ struct MeasureState {
   uint64_t n_type_entries = 0, n_cc_rows = 0;
 };
 
+constexpr int kFileStages = 8;  // pinned 32 MiB buffers between a file and the device
+
+// Where the time of the last dx_part_write_layout went (wall clock of the calling thread unless said otherwise).
+struct LayoutTimes {
+  double total_ms = 0;
+  double prepare_ms = 0;     // directories, text files, the list of files
+  double encode_ms = 0;      // page bodies on the GPU (with the host's planning of the files between its two passes)
+  double d2h_ms = 0;         // the files' bytes coming to pinned host memory; the writing threads run meanwhile
+  double write_wall_ms = 0;  // first write started .. last write done
+  double write_busy_ms = 0;  // summed over the writing threads
+  uint64_t bytes = 0;        // written through the image (everything but the small text files)
+  int threads = 0;
+};
+
 struct CatalogTable {
   std::string key;      // "00001-_3=<pred>"
   std::string view;     // "table00001__3_E_<pred>"
@@ -125,6 +139,7 @@ struct dx_ctx {
   dx::Dictionary dict;
   dx::PartitionState part;
   dx::MeasureState measures;
+  dx::LayoutTimes layout_times;
   std::map<std::string, dx::CatalogTable> catalog;   // by view name
   std::map<std::string, std::pair<uint64_t, uint64_t>> table_stats;  // by table key: distinct s, distinct o
   // Vertical-partition tables brought in from a layout's Parquet files (dx_import_layout), by table key: resident id
@@ -140,8 +155,8 @@ struct dx_ctx {
   void* q_host = nullptr;               // pinned block the final counters of a statement land in
   void* q_host_dev = nullptr;           // the same block as the device addresses it
   uint64_t q_seq = 0;                   // statements run on this context so far
-  void* file_stage[2] = {nullptr, nullptr};        // pinned buffers dx_partition_file streams a file through
-  hipEvent_t file_stage_ev[2] = {nullptr, nullptr};
+  void* file_stage[dx::kFileStages] = {};          // pinned buffers dx_partition_file streams a file through
+  hipEvent_t file_stage_ev[dx::kFileStages] = {};
   void* q_counters = nullptr;           // device: a statement's row counters and its last-block ticket, zero between statements
   std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
   // Statements come again: the parsed form is kept per text, and the join order the search found per (text, numbers the
@@ -337,6 +352,24 @@ class ParquetWriter {
  private:
   Impl* p;
 };
+// The same format for page bodies that are encoded on the GPU (dx_layout.hip). Per column chunk the caller states the
+// sizes of its pages: a dictionary page of n_dict entries in dict_bytes plus bit-packed indices, or (plain) one page of
+// plain_bytes of length-prefixed values. The plan gives the file's size, every byte of it that is not a page body
+// (as (file offset, bytes) pieces in file order) and the file offsets of the bodies.
+constexpr uint64_t kParquetRowGroupRows = 1u << 20;
+struct PqChunkIn { uint64_t num_values = 0, n_dict = 0, dict_bytes = 0; bool plain = false; uint64_t plain_bytes = 0; };
+struct PqChunkOut { uint64_t dict_at = 0, data_at = 0, data_bytes = 0; uint32_t width = 0; };
+struct PqFilePlan { uint64_t size = 0; std::vector<std::pair<uint64_t, std::string>> host; std::vector<PqChunkOut> chunks; };
+// chunks: row group after row group, inside a group column after column
+PqFilePlan plan_parquet_file(const std::vector<std::string>& names, const std::vector<uint64_t>& group_rows, const std::vector<PqChunkIn>& chunks);
+
+// dx_layout.hip: the reference's on-disk layout from what a partition run left in HBM (dx_part_write_layout)
+void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir);
+// dx_api.cpp: small helpers of the layout code
+void mkdirs(const std::string& path);
+void touch(const std::string& path);
+std::string part_name(int i);
+std::string norm_base(const char* base);
 
 // dx_hp1.hip
 void run_partition(dx_ctx* ctx, const uint8_t* d_text, uint64_t n_bytes, const std::vector<ClassIndexEntry>& classes,

@@ -28,7 +28,7 @@ EXPORTS = [
     "dx_term_count", "dx_terms_bytes", "dx_terms_decode", "dx_terms_lookup", "dx_part_count", "dx_part_rows",
     "dx_part_fetch", "dx_table_count", "dx_table_info_at", "dx_table_fetch", "dx_node_index_rows",
     "dx_node_index_fetch", "dx_vp_index_rows", "dx_vp_index_fetch", "dx_instance_graph_sizes",
-    "dx_instance_graph_fetch", "dx_part_write_layout", "dx_open_dataset", "dx_load_table", "dx_unload_all",
+    "dx_instance_graph_fetch", "dx_part_write_layout", "dx_layout_times", "dx_open_dataset", "dx_load_table", "dx_unload_all",
     "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
@@ -111,6 +111,7 @@ def load_library():
         "dx_measures_cc": (c_int, [c_void_p, i64p, i64p, i64p, i64p, i64p]),
         "dx_measures_write": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
         "dx_part_write_layout": (c_int, [c_void_p, c_char_p, c_char_p, c_char_p]),
+        "dx_layout_times": (c_int, [c_void_p, POINTER(c_double), c_int]),
         "dx_open_dataset": (c_int, [c_void_p, c_char_p, c_char_p, c_int]),
         "dx_import_layout": (c_int, [c_void_p, c_char_p, c_char_p, c_int, u64p, u64p]),
         "dx_load_table": (c_int, [c_void_p, c_char_p, u64p]),
@@ -363,6 +364,13 @@ class Engine:
 
     def write_layout(self, base: str, dataset: str, local_dir: str = ""):
         self._check(self.lib.dx_part_write_layout(self.ctx, base.encode(), dataset.encode(), local_dir.encode()))
+
+    def layout_times(self) -> dict:
+        """Where the time of the last write_layout went (ms), the bytes it wrote and the threads that wrote them."""
+        v = (c_double * 8)()
+        self._check(self.lib.dx_layout_times(self.ctx, v, 8))
+        keys = ("total_ms", "prepare_ms", "encode_ms", "d2h_ms", "write_wall_ms", "write_busy_ms", "bytes", "threads")
+        return {k: (int(x) if k in ("bytes", "threads") else float(x)) for k, x in zip(keys, v)}
 
     # ---- query processor ---------------------------------------------------------------
     def open_dataset(self, base: str, dataset: str, n_partitions: int):

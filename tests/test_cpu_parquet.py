@@ -140,16 +140,19 @@ def test_native_parquet_writer_is_read_back_by_pyarrow(tmp_path):
 
     def term(k):
         return '"h\u00e9llo \U0001F642"@fr' if k == 1 else "<t%d>" % k + "x" * (k % 97)
-    for rows, codec in ((0, ""), (1, ""), (9, "snappy"), (3000000, ""), (3000000, "snappy"), (0, "snappy")):
+    # "plan": the file laid out by plan_parquet_file from page sizes, the bodies dropped in (what the GPU encoder's host side does)
+    for rows, codec in ((0, ""), (1, ""), (9, "snappy"), (3000000, ""), (3000000, "snappy"), (0, "snappy"), (0, "plan"), (1, "plan"), (9, "plan"),
+                        (2500000, "plan")):
         out = str(tmp_path / ("t%d%s.parquet" % (rows, codec)))
-        r = subprocess.run([exe, out, str(rows), str(T)], capture_output=True, text=True, timeout=300, env=dict(os.environ, DX_PARQUET_CODEC=codec))
+        r = subprocess.run([exe, out, str(rows), str(T)] + (["plan"] if codec == "plan" else []), capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DX_PARQUET_CODEC="" if codec == "plan" else codec))
         assert r.returncode == 0, r.stderr
         t = pq.read_table(out)
         assert t.column_names == ["_1", "_2", "parts"] and t.num_rows == rows
         md = pq.ParquetFile(out).metadata
         if rows:
-            assert md.row_group(0).column(0).compression == ("SNAPPY" if codec else "UNCOMPRESSED")
-        if rows == 3000000 and codec:  # the terms of the test compress well; the bit-packed indices hardly
+            assert md.row_group(0).column(0).compression == ("SNAPPY" if codec == "snappy" else "UNCOMPRESSED")
+        if rows == 3000000 and codec == "snappy":  # the terms of the test compress well; the bit-packed indices hardly
             assert os.path.getsize(out) < 0.7 * os.path.getsize(str(tmp_path / "t3000000.parquet"))
         assert md.num_row_groups >= (rows + (1 << 20) - 1) // (1 << 20) and md.num_rows == rows
         a, b, c = t["_1"].to_pylist(), t["_2"].to_pylist(), t["parts"].to_pylist()
