@@ -251,10 +251,12 @@ typedef struct dx_comm {
                   int elem_bytes);
   /* element-wise sum of n <= 1024 host values over all ranks, result on every rank */
   int (*allreduce_sum)(void* user, uint64_t* values, int n);
-  /* the partitioner's collectives (may be NULL when only queries run on several GPUs):
-   * recv_dev = the ranks' send buffers one after another in rank order (recv_counts[p] elements from p) */
+  /* recv_dev = the ranks' send buffers one after another in rank order (recv_counts[p] elements from p). Needed by the
+   * partitioner and by the queries (a small join side and a cross product go to every rank through it): dx_set_comm
+   * refuses a group of several ranks without it. */
   int (*allgather)(void* user, const void* send_dev, uint64_t send_count, void* recv_dev, const uint64_t* recv_counts, int elem_bytes);
-  /* element-wise sum of a device array of n elements of 1 or 8 bytes, in place, result on every rank */
+  /* element-wise sum of a device array of n elements of 1 or 8 bytes, in place, result on every rank; the partitioner's
+   * and the measures' (may be NULL when only queries run on several GPUs) */
   int (*allreduce_sum_dev)(void* user, void* dev, uint64_t n, int elem_bytes);
   /* 0: the three device collectives return when their result is complete, and the library waits for its own
    *    stream before it calls them.
@@ -272,14 +274,20 @@ int dx_set_comm(dx_ctx* ctx, const dx_comm* comm);
 /* The communicator over RCCL, made inside the library (replaces the executors' shuffle service Spark brings up
  * with the session, QueryProcessor.scala:116-154, DAP.scala:41-48). Rank 0 makes a unique id and hands its
  * DX_RCCL_ID_BYTES bytes to the other ranks by any means; then every rank calls dx_comm_rccl_init with its own
- * context (one GPU per rank; the call returns when all `world` ranks have made it). dx_comm_rccl_init_file does
- * both over a path all ranks can reach: rank 0 writes the id there, the others wait up to timeout_ms for it.
+ * context (one GPU per rank; the call returns when all `world` ranks have made it, or with DX_E_IO when they have not
+ * all arrived within DX_RCCL_INIT_TIMEOUT_MS, 10 minutes by default: the process should then end). dx_comm_rccl_init_file
+ * does both over a path all ranks can reach: rank 0 removes what lies there, writes the id, and removes the file again
+ * once the group has formed; the others wait up to timeout_ms for the file, and every rank up to timeout_ms for the
+ * group. dx_comm_rccl_init_job is the same with the number of the job in the file's name (`path.<job in hex>`; any
+ * number that the ranks of one launch share and other launches do not), so that a file which a launch that died has left
+ * behind is never read; without it such a file can cost the rank that read it its timeout_ms.
  * The collectives are queued on the context's stream. dx_set_comm(ctx, NULL), another dx_comm_rccl_init and
  * dx_free leave the group. world == 1 is single-GPU execution. */
 #define DX_RCCL_ID_BYTES 128
 int dx_rccl_unique_id(unsigned char id[DX_RCCL_ID_BYTES]);
 int dx_comm_rccl_init(dx_ctx* ctx, const unsigned char id[DX_RCCL_ID_BYTES], int rank, int world);
 int dx_comm_rccl_init_file(dx_ctx* ctx, const char* path, int rank, int world, int timeout_ms);
+int dx_comm_rccl_init_job(dx_ctx* ctx, const char* path, uint64_t job, int rank, int world, int timeout_ms);
 /* Drives each of the communicator's collectives once with known patterns on small device buffers and checks
  * what arrives (a collective call; every rank checks its own share). Meant to be called once after the group has
  * been formed, before a long job relies on it. DX_E_IO with the first mismatch in dx_last_error. */

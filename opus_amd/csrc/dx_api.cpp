@@ -1260,8 +1260,9 @@ int dx_set_comm(dx_ctx* ctx, const dx_comm* comm) {
       ctx->comm.world = 1;
       return;
     }
-    if (comm->rank < 0 || comm->rank >= comm->world || !comm->exchange_host || !comm->exchange || !comm->allreduce_sum)
-      throw DxError(DX_E_INVAL, "dx_set_comm: rank out of range or a collective is missing");
+    // allgather serves the queries too (a small join side, a cross product, goes to every rank through it)
+    if (comm->rank < 0 || comm->rank >= comm->world || !comm->exchange_host || !comm->exchange || !comm->allreduce_sum || !comm->allgather)
+      throw DxError(DX_E_INVAL, "dx_set_comm: rank out of range or a collective is missing (exchange_host, exchange, allreduce_sum and allgather are needed)");
     if (comm->world > 64) throw DxError(DX_E_RANGE, "dx_set_comm: more than 64 ranks");
     ctx->comm = *comm;
   });
@@ -1282,18 +1283,30 @@ int dx_rccl_unique_id(unsigned char id[DX_RCCL_ID_BYTES]) {
 int dx_comm_rccl_init(dx_ctx* ctx, const unsigned char id[DX_RCCL_ID_BYTES], int rank, int world) {
   return guard(ctx, [&] {
     if (!id) throw DxError(DX_E_INVAL, "null unique id");
-    rccl_comm_create(ctx, id, rank, world);
+    rccl_comm_create(ctx, id, rank, world, 0);
+  });
+}
+
+int dx_comm_rccl_init_job(dx_ctx* ctx, const char* path, uint64_t job, int rank, int world, int timeout_ms) {
+  return guard(ctx, [&] {
+    if (!path) throw DxError(DX_E_INVAL, "null path");
+    unsigned char id[DX_RCCL_ID_BYTES];
+    const int wait_ms = timeout_ms > 0 ? timeout_ms : 60000;
+    const std::string file = rccl_rendezvous_name(path, job);
+    if (world > 1) rccl_rendezvous_file(file, rank, wait_ms, id);
+    else rccl_unique_id(id);  // a group of one rank has nobody to meet
+    try {
+      rccl_comm_create(ctx, id, rank, world, wait_ms);
+    } catch (...) {
+      if (world > 1 && rank == 0) rccl_rendezvous_done(file);
+      throw;
+    }
+    if (world > 1 && rank == 0) rccl_rendezvous_done(file);
   });
 }
 
 int dx_comm_rccl_init_file(dx_ctx* ctx, const char* path, int rank, int world, int timeout_ms) {
-  return guard(ctx, [&] {
-    if (!path) throw DxError(DX_E_INVAL, "null path");
-    unsigned char id[DX_RCCL_ID_BYTES];
-    if (world > 1) rccl_rendezvous_file(path, rank, timeout_ms > 0 ? timeout_ms : 60000, id);
-    else rccl_unique_id(id);  // a group of one rank has nobody to meet
-    rccl_comm_create(ctx, id, rank, world);
-  });
+  return dx_comm_rccl_init_job(ctx, path, 0, rank, world, timeout_ms);
 }
 
 int dx_comm_selftest(dx_ctx* ctx) {

@@ -22,7 +22,9 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <fstream>
+#include <mutex>
 #include <thread>
 
 #include "dx_state.h"
@@ -95,6 +97,17 @@ namespace {
       return 1;                                                                                  \
     }                                                                                            \
   } while (0)
+// inside ncclGroupStart .. ncclGroupEnd: the group is closed before the error is returned, so that the calls that
+// follow do not nest in it
+#define DX_NCCL_IN_GROUP(c, expr)                                                                \
+  do {                                                                                           \
+    ncclResult_t _r = (expr);                                                                    \
+    if (_r != ncclSuccess) {                                                                     \
+      (c)->last_error = std::string(#expr) + ": " + rccl().GetErrorString(_r);                   \
+      (void)rccl().GroupEnd();                                                                   \
+      return 1;                                                                                  \
+    }                                                                                            \
+  } while (0)
 #define DX_HIPRC(c, expr)                                                                        \
   do {                                                                                           \
     hipError_t _e = (expr);                                                                      \
@@ -126,8 +139,8 @@ int rc_exchange(void* user, const void* send_dev, const uint64_t* send_counts, v
       self_so = so;
       self_ro = ro;
     } else {
-      if (ns) DX_NCCL(c, api.Send(sp + so, ns, ty, p, c->comm, c->stream));
-      if (nr) DX_NCCL(c, api.Recv(rp + ro, nr, ty, p, c->comm, c->stream));
+      if (ns) DX_NCCL_IN_GROUP(c, api.Send(sp + so, ns, ty, p, c->comm, c->stream));
+      if (nr) DX_NCCL_IN_GROUP(c, api.Recv(rp + ro, nr, ty, p, c->comm, c->stream));
     }
     so += send_counts[p] * (size_t)elem_bytes;
     ro += recv_counts[p] * (size_t)elem_bytes;
@@ -153,8 +166,8 @@ int rc_allgather(void* user, const void* send_dev, uint64_t send_count, void* re
     if (p == c->rank) {
       self_ro = ro;
     } else {
-      if (ns) DX_NCCL(c, api.Send(send_dev, ns, ty, p, c->comm, c->stream));
-      if (nr) DX_NCCL(c, api.Recv(rp + ro, nr, ty, p, c->comm, c->stream));
+      if (ns) DX_NCCL_IN_GROUP(c, api.Send(send_dev, ns, ty, p, c->comm, c->stream));
+      if (nr) DX_NCCL_IN_GROUP(c, api.Recv(rp + ro, nr, ty, p, c->comm, c->stream));
     }
     ro += recv_counts[p] * (size_t)elem_bytes;
   }
@@ -224,25 +237,71 @@ void rccl_unique_id(unsigned char* out) {
   memcpy(out, id.internal, DX_RCCL_ID_BYTES);
 }
 
-void rccl_comm_create(dx_ctx* ctx, const unsigned char* id_bytes, int rank, int world) {
+// ncclCommInitRank returns when every rank of the group has called it and has no time limit of its own: a rank whose
+// peers never come (one of them failed before it got here, or read the id of another job) would wait for ever. The call
+// therefore runs on a thread of its own; when it has not come back after timeout_ms the caller gets DX_E_IO, and the
+// thread, which cannot be called back, is left to itself with everything it uses (the process is expected to end).
+void rccl_comm_create(dx_ctx* ctx, const unsigned char* id_bytes, int rank, int world, int timeout_ms) {
   if (world < 1 || world > 64 || rank < 0 || rank >= world) throw DxError(DX_E_INVAL, "rank / world out of range (at most 64 ranks)");
   rccl_comm_destroy(ctx);
   // (a group of one rank is a real RCCL communicator too: the engine runs as on a single GPU, since world == 1,
   // and dx_comm_selftest can drive the collectives through it)
+  RcclApi& api = rccl();
+  if (timeout_ms <= 0) {
+    const char* e = getenv("DX_RCCL_INIT_TIMEOUT_MS");
+    timeout_ms = e && atoi(e) > 0 ? atoi(e) : 600000;
+  }
+  struct Init {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t result = ncclSuccess;
+    ncclComm_t comm = nullptr;
+    ncclUniqueId id;
+  };
+  auto init = std::make_shared<Init>();
+  memcpy(init->id.internal, id_bytes, DX_RCCL_ID_BYTES);
+  const int device = ctx->device;
+  std::thread([init, device, rank, world, &api] {
+    (void)hipSetDevice(device);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = api.CommInitRank(&comm, world, init->id, rank);
+    std::unique_lock<std::mutex> l(init->mu);
+    if (init->abandoned) {  // nobody is waiting any more: the group that formed after all is left again
+      l.unlock();
+      if (r == ncclSuccess && comm) (void)api.CommDestroy(comm);
+      return;
+    }
+    init->result = r;
+    init->comm = comm;
+    init->done = true;
+    init->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> l(init->mu);
+    if (!init->cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return init->done; })) {
+      init->abandoned = true;
+      throw DxError(DX_E_IO, "ncclCommInitRank: the " + std::to_string(world) + " ranks of the group did not all arrive within " + std::to_string(timeout_ms) + " ms");
+    }
+  }
+  if (init->result != ncclSuccess) throw DxError(DX_E_IO, std::string("ncclCommInitRank: ") + api.GetErrorString(init->result));
   auto c = std::make_unique<RcclComm>();
+  c->comm = init->comm;
   c->device = ctx->device;
   c->rank = rank;
   c->world = world;
   c->stream = ctx->stream;
-  ncclUniqueId id;
-  memcpy(id.internal, id_bytes, DX_RCCL_ID_BYTES);
-  const ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);  // blocks until every rank of the group has called it
-  if (r != ncclSuccess) throw DxError(DX_E_IO, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
-  void* p = nullptr;
-  DX_HIP(hipHostMalloc(&p, 2 * kHostWords * 8, hipHostMallocDefault));
-  c->pinned = static_cast<uint64_t*>(p);
-  DX_HIP(hipMalloc(&p, 2 * kHostWords * 8));
-  c->dev = static_cast<uint64_t*>(p);
+  try {
+    void* p = nullptr;
+    DX_HIP(hipHostMalloc(&p, 2 * kHostWords * 8, hipHostMallocDefault));
+    c->pinned = static_cast<uint64_t*>(p);
+    DX_HIP(hipMalloc(&p, 2 * kHostWords * 8));
+    c->dev = static_cast<uint64_t*>(p);
+  } catch (...) {  // the group must not outlive a half-made communicator
+    (void)api.CommDestroy(c->comm);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    throw;
+  }
   dx_comm cm{};
   cm.rank = rank;
   cm.world = world;
@@ -257,11 +316,25 @@ void rccl_comm_create(dx_ctx* ctx, const unsigned char* id_bytes, int rank, int 
   ctx->native_comm = c.release();
 }
 
-// Rank 0 writes the id to `path` (through a temporary name, so that a reader never sees half of it), the others
-// wait for the file to appear. Any path all ranks can read will do; rank 0 removes nothing: the caller owns the path.
-void rccl_rendezvous_file(const char* path, int rank, int timeout_ms, unsigned char* id) {
-  const std::string p = path;
+// The file a job's ranks meet at: `path` itself, or `path.<job in hex>` when the caller names the job (any number all
+// ranks of one launch share and other launches do not: a launcher's job id, its rendezvous port and start time). With a
+// job number a file left by an earlier launch has another name and is never read.
+std::string rccl_rendezvous_name(const char* path, uint64_t job) {
+  if (!job) return path;
+  char suffix[32];
+  snprintf(suffix, sizeof suffix, ".%llx", (unsigned long long)job);
+  return std::string(path) + suffix;
+}
+void rccl_rendezvous_done(const std::string& file) { (void)unlink(file.c_str()); }
+
+// Rank 0 removes whatever lies at the name, then writes the id there (through a temporary name, so that a reader never
+// sees half of it); the others wait for the file to appear. Rank 0 removes the file again once the group has formed
+// (rccl_rendezvous_done): every rank has read it by then. Without a job number in the name one case is left open: a
+// file that a launch which died before its group formed has left behind, read by a rank that starts before this launch's
+// rank 0 has removed it -- that rank then waits in ncclCommInitRank until its time limit and returns DX_E_IO.
+void rccl_rendezvous_file(const std::string& p, int rank, int timeout_ms, unsigned char* id) {
   if (rank == 0) {
+    (void)unlink(p.c_str());
     rccl_unique_id(id);
     const std::string tmp = p + ".tmp" + std::to_string((long)getpid());
     {

@@ -1384,6 +1384,7 @@ struct ShardedRun {
     DevBuf<int64_t> send(pool, std::max<uint64_t>(in.rows * in.ncols, 1)), recv(pool, std::max<uint64_t>(total * in.ncols, 1));
     if (in.rows) hipLaunchKernelGGL(k_pack_rows, dim3(scan_grid(in.rows)), dim3(256), 0, s, row_cols(in), (uint32_t)in.rows, send.p);
     before_collective();
+    if (!cm.allgather) throw DxError(DX_E_INVAL, "the communicator has no allgather");
     comm_check(cm.allgather(cm.user, send.p, in.rows * in.ncols, recv.p, counts.data(), 8), "allgather of a relation");
     ++n_data_collectives;
     DevRel full = make_rel(in.ncols, total);
@@ -1454,7 +1455,20 @@ dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode) {
     if (single && owner >= 0 && !getenv("DX_NO_SINGLE_OWNER")) {
       LocalError err;
       dx_result* res = nullptr;
-      if (cm.rank == owner) run_local(err, [&] { res = run_query(ctx, sql, mode); });
+      // The owner is read off the tables' names; tables placed otherwise (dx_load_table + dx_declare_remote_table with
+      // another rule than partition % world) would be scanned as empty here: the owner refuses, and the sum below
+      // brings its refusal to every rank.
+      if (cm.rank == owner)
+        run_local(err, [&] {
+          for (const SqlSub& sub : q.subs)
+            for (const SqlArm& arm : sub.arms) {
+              auto it = ctx->catalog.find(arm.table);
+              if (it != ctx->catalog.end() && it->second.remote)
+                throw DxError(DX_E_INVAL, "table " + arm.table + " belongs to partition " + arm.table.substr(5, 5) + ", which rank " + std::to_string(owner) +
+                                              " of " + std::to_string(W) + " owns (partition % ranks), but it is declared as held by another rank");
+            }
+          res = run_query(ctx, sql, mode);
+        });
       try {
         uint64_t fin[1 + kErrSlots] = {0};
         fin[0] = (err || !res) ? 0 : res->count;

@@ -392,9 +392,11 @@ dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode);
 extern const char* const kStageNames[12];
 // dx_comm_rccl.cpp
 void rccl_unique_id(unsigned char* out);
-void rccl_comm_create(dx_ctx* ctx, const unsigned char* id_bytes, int rank, int world);
+void rccl_comm_create(dx_ctx* ctx, const unsigned char* id_bytes, int rank, int world, int timeout_ms);
 void rccl_comm_destroy(dx_ctx* ctx);
-void rccl_rendezvous_file(const char* path, int rank, int timeout_ms, unsigned char* id);
+std::string rccl_rendezvous_name(const char* path, uint64_t job);
+void rccl_rendezvous_file(const std::string& file, int rank, int timeout_ms, unsigned char* id);
+void rccl_rendezvous_done(const std::string& file);
 const char* rccl_comm_last_error(dx_ctx* ctx);
 
 // ---- agreement between ranks ---------------------------------------------------------------------------

@@ -33,7 +33,7 @@ EXPORTS = [
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
     "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
-    "dx_query_count_noalloc", "dx_rccl_unique_id", "dx_comm_rccl_init", "dx_comm_rccl_init_file", "dx_comm_selftest",
+    "dx_query_count_noalloc", "dx_rccl_unique_id", "dx_comm_rccl_init", "dx_comm_rccl_init_file", "dx_comm_rccl_init_job", "dx_comm_selftest",
     "dx_load_tables_sharded", "dx_import_layout",
 ]
 
@@ -133,6 +133,7 @@ def load_library():
         "dx_rccl_unique_id": (c_int, [c_void_p]),
         "dx_comm_rccl_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
         "dx_comm_rccl_init_file": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int]),
+        "dx_comm_rccl_init_job": (c_int, [c_void_p, c_char_p, c_uint64, c_int, c_int, c_int]),
         "dx_comm_selftest": (c_int, [c_void_p]),
         "dx_load_tables_sharded": (c_int, [c_void_p, POINTER(c_char_p), c_int, u64p]),
         "dx_declare_remote_table": (c_int, [c_void_p, c_char_p]),
@@ -432,9 +433,10 @@ class Engine:
         self._comm = None
         self._check(self.lib.dx_comm_rccl_init(self.ctx, ctypes.create_string_buffer(unique_id, 128), rank, world))
 
-    def comm_rccl_init_file(self, path: str, rank: int, world: int, timeout_ms: int = 60000):
+    def comm_rccl_init_file(self, path: str, rank: int, world: int, timeout_ms: int = 60000, job: int = 0):
+        """job: a number the ranks of this launch share and other launches do not (it goes into the file's name)."""
         self._comm = None
-        self._check(self.lib.dx_comm_rccl_init_file(self.ctx, path.encode(), rank, world, timeout_ms))
+        self._check(self.lib.dx_comm_rccl_init_job(self.ctx, path.encode(), job, rank, world, timeout_ms))
 
     def comm_selftest(self):
         self._check(self.lib.dx_comm_selftest(self.ctx))

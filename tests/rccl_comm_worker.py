@@ -66,6 +66,32 @@ def main(out_path):
     e.comm_rccl_init_file(out_path + ".rccl_id", 0, 1)
     e.comm_selftest()
     res["selftest_native_file"] = True
+    # The meeting point of a group of two with only one rank present: nothing may wait for ever.
+    from opus_amd.engine import DxError
+    import time
+    # rank 1 finds only the file of another launch (another job number): no id within its time limit
+    stale = out_path + ".meet"
+    open(stale + ".7", "wb").write(b"\x01" * 128)
+    t0 = time.time()
+    try:
+        e.comm_rccl_init_file(stale, 1, 2, timeout_ms=300, job=8)
+        res["waiter_without_rank0"] = 0
+    except DxError as ex:
+        res["waiter_without_rank0"] = ex.code
+    res["waiter_seconds"] = time.time() - t0
+    # rank 0 replaces a file left at the plain name, waits for a peer that never comes, gives up after its time limit and
+    # takes its file away again
+    open(stale, "wb").write(b"\x02" * 128)
+    t0 = time.time()
+    try:
+        e.comm_rccl_init_file(stale, 0, 2, timeout_ms=1500)
+        res["rank0_without_peer"] = 0
+    except DxError as ex:
+        res["rank0_without_peer"] = ex.code
+    res["rank0_seconds"] = time.time() - t0
+    res["file_left"] = os.path.exists(stale)
+    e.comm_rccl_init(Engine.rccl_unique_id(), 0, 1)   # the context still forms groups
+    e.comm_selftest()
     # with a group of one rank the engine works as on a single GPU
     st = e.partition_text(b"<a> <p> <b> .\n<a> <http://www.w3.org/1999/02/22-rdf-syntax-ns#type> <C> .\n", "<C>\t0", 1)
     res["partition_rows"] = int(st.n_rows)
@@ -74,7 +100,12 @@ def main(out_path):
 
     dist.barrier()
     dist.destroy_process_group()
-    json.dump(res, open(out_path, "w"))
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    # the thread that still waits for the peer that never came cannot be called back: leave without the interpreter's
+    # and the libraries' exit handlers, which might wait for it
+    sys.stdout.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

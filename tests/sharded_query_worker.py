@@ -137,6 +137,27 @@ def main(out_path):
     e.load_tables_sharded(parts1)
     failures["owner_after"] = e.query(sql1, DX_QUERY_COUNT).count
     failures["owner_want_after"] = results[own_name]["count"]
+    # tables placed by another rule than partition % world (the public calls allow it): the rank the names point at holds
+    # none of them, so the one-rank shortcut must refuse on every rank instead of counting nothing; through the
+    # exchanges the same placement answers correctly
+    other = lambda q: (owner(q) + 1) % world  # noqa: E731
+    e.unload_all()
+    load_tables_sharded(e, comm, parts1, other)
+    try:
+        e.query(sql1, DX_QUERY_COUNT)
+        failures["other_placement_shortcut"] = 0
+    except DxError as ex:
+        failures["other_placement_shortcut"] = ex.code
+    os.environ["DX_NO_SINGLE_OWNER"] = "1"
+    failures["other_placement_exchanges"] = e.query(sql1, DX_QUERY_COUNT).count
+    os.environ.pop("DX_NO_SINGLE_OWNER", None)
+    # a communicator of several ranks without allgather is refused when it is set, not when a join first needs it
+    import ctypes
+    from opus_amd.host.comm import ALLGATHER_FN, DxComm
+    st = comm.struct
+    bare = DxComm(st.rank, st.world, None, st.exchange_host, st.exchange, st.allreduce_sum, ALLGATHER_FN(), st.allreduce_sum_dev, 0)
+    failures["no_allgather"] = e.lib.dx_set_comm(e.ctx, ctypes.byref(bare))
+    e.set_comm(comm)
     all_f = [None] * world
     dist.all_gather_object(all_f, failures)
     if rank == 0:

@@ -34,3 +34,5 @@ def test_callbacks_over_rccl_single_rank(tmp_path):
     assert r["allreduce_rc"] == 0 and r["allreduce"] == [5, 11]
     assert r["selftest_torch"] and r["selftest_native"] and r["selftest_native_file"]
     assert r["partition_rows"] == 2
+    assert r["waiter_without_rank0"] == -5 and r["waiter_seconds"] < 5
+    assert r["rank0_without_peer"] == -5 and r["rank0_seconds"] < 20 and not r["file_left"]

@@ -36,6 +36,8 @@ def test_two_ranks_answer_like_one(tmp_path):
         assert f["missing_table"] == -2 and f["missing_file"] == -2, failures
         assert f["after"] == f["want_after"]
         assert f["owner_lost_table"] == -2 and f["owner_after"] == f["owner_want_after"], failures
+        assert f["other_placement_shortcut"] == -22 and f["other_placement_exchanges"] == f["owner_want_after"], failures
+        assert f["no_allgather"] == -22, failures
     assert len(res) >= 42
     # statements whose tables all lie in one rank's partitions: answered there, one sum, no rows moved
     alone_runs = [n for n, r in res.items() if n.endswith("#owner") and "alone: all tables in its partitions" in r["plan"]]
