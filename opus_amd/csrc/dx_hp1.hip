@@ -1239,8 +1239,9 @@ k_place(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t type_pid
       bool nf = is_type && m != 0;
       if (fresh[j]) {
         // With several ranks a triple reaches every owner of one of its partitions: the owner of the lowest
-        // one counts it and keeps its node-index row (one GPU: owned = all ones, so always).
-        const bool mine = m == 0 ? owned == ~0ull : ((m & (~m + 1)) & owned) != 0;
+        // one counts it and keeps its node-index row (one GPU: owned = all ones, so always). A triple that no
+        // partition takes has been sent to one rank only.
+        const bool mine = m == 0 || ((m & (~m + 1)) & owned) != 0;
         if (mine) {
           ++uq;
           if (!is_type && !(fo[j] & kFlagLiteral)) ++ed;
@@ -1774,7 +1775,11 @@ k_route_count(const K* __restrict__ keys, uint32_t n, int bits_term, uint32_t ty
   if (threadIdx.x < DX_MAX_PARTITIONS) c[threadIdx.x] = 0;
   __syncthreads();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t d = owners_of(placement(unpack(keys[i], bits_term), type_pidx, flags, Pm, M), world);
+    const K key = keys[i];
+    uint64_t d = owners_of(placement(unpack(key, bits_term), type_pidx, flags, Pm, M), world);
+    // a triple that no partition takes still counts among the distinct triples (and edges) of the input: it goes to
+    // one rank, chosen by its own bits, where its copies from other ranks' texts meet it
+    if (!d) d = 1ull << (mix64((uint64_t)key ^ (uint64_t)(key >> 32 >> 32)) % (uint64_t)world);
     owners[i] = d;
     for (uint64_t x = d; x; x &= x - 1) atomicAdd(&c[__ffsll((long long)x) - 1], 1u);
   }

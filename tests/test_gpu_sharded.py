@@ -62,21 +62,25 @@ def test_two_ranks_answer_like_one(tmp_path):
     assert res["Q2.txt#hashed"]["plan"] != res["Q2.txt"]["plan"]
 
 
-@pytest.mark.parametrize("wide_keys", ["0", "1"])
-def test_two_ranks_partition_like_one(tmp_path, wide_keys):
-    """Each rank tokenises its half of the text; the ranks agree on one dictionary, exchange vertex facts and
+# (ranks, first-level partitions, 128-bit key words): two ranks as before; four ranks over eight partitions (two each);
+# eight ranks over four partitions, where half the ranks own no partition at all and still take part in every collective
+@pytest.mark.parametrize("ranks,parts,wide_keys", [(2, 4, "0"), (2, 4, "1"), (4, 8, "0"), (8, 4, "0"), (8, 8, "1")])
+def test_ranks_partition_like_one(tmp_path, ranks, parts, wide_keys):
+    """Each rank tokenises its piece of the text; the ranks agree on one dictionary, exchange vertex facts and
     route the triples to the owners of their partitions. Together they must hold exactly what one GPU
     produces from the whole text, and answer the queries alike."""
     out = tmp_path / "sharded_partition.json"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "sharded_partition_worker.py"), str(out)]
     # wide_keys: the 128-bit key words of a very large dictionary, forced on this small one (16 bytes per routed triple)
-    env = dict(os.environ, DX_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DX_FORCE_WIDE_KEYS=wide_keys)
+    env = dict(os.environ, DX_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DX_FORCE_WIDE_KEYS=wide_keys, DX_TEST_PARTS=str(parts),
+               DX_TEST_UNIVERSITIES="2" if ranks == 2 else "3")
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     res = json.load(open(out))
     shares, alone = res["shares"], res["alone"]
     world = len(shares)
+    assert world == ranks and len(alone["parts"]) == parts
     assert sum(s["n_triples_in"] for s in shares) == res["n_triples"]
     for s in shares:
         assert s["n_terms"] == alone["n_terms"]                       # one dictionary
@@ -86,7 +90,9 @@ def test_two_ranks_partition_like_one(tmp_path, wide_keys):
     assert len(alone["measures"]["cc"]) > 20
     for s in shares:   # schema_cc, node frequency and node count over all ranks' triples, the same on every rank
         assert s["measures"] == alone["measures"]
-    assert shares[0]["n_edges"] <= alone["n_edges"] and shares[0]["n_unique"] <= alone["n_unique"]  # placed ones only
+    # distinct triples and edges of the whole input, placed or not, counted once wherever their copies were read
+    assert shares[0]["n_edges"] == alone["n_edges"] and shares[0]["n_unique"] == alone["n_unique"]
+    assert alone["n_unique"] == res["n_distinct_lines"] < res["n_triples"]   # the worker states one triple twice, in two ranks' parts
     for q, want in enumerate(alone["parts"]):
         for s in shares:
             if s["rank"] == q % world:
@@ -104,7 +110,7 @@ def test_two_ranks_partition_like_one(tmp_path, wide_keys):
             if s["rank"] != owner:
                 assert s["vp_index"].get(pname, []) == [], "rank %d holds VP-index rows of partition %s" % (s["rank"], pname)
     assert sum(s["n_vp_index"] for s in shares) == alone["n_vp_index"]
-    assert res["malformed"] == [-74, -74]   # one rank's text is malformed: both ranks return DX_E_MALFORMED
+    assert res["malformed"] == [-74] * world   # one rank's text is malformed: every rank returns DX_E_MALFORMED
     assert len(res["queries"]) == 13
     for name, r in res["queries"].items():
         assert r["count"] == r["want_count"] and r["columns"] == r["want_columns"] and r["rows"] == r["want_rows"], name
