@@ -12,7 +12,7 @@ _LIB = None
 def _lib():
     global _LIB
     if _LIB is None:
-        lib = ctypes.CDLL(os.path.join(_HERE, "_ref", "libcpu_port.so"))
+        lib = ctypes.CDLL(os.path.join(_HERE, "_build", "libcpu_port.so"))
         lib.cpu_port_run.restype = ctypes.c_void_p
         lib.cpu_port_run.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         lib.cpu_port_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -28,10 +28,15 @@ def test_edge_case_graphs(tmp_path):
     """Every hand-made graph of the partitioner's edge cases as files: empty partitions, predicates that share a
     directory, predicates of 150 units and more (in the part files, in no directory), non-BMP characters, an input
     that places nothing at all."""
+    import json
     from parity_util import assert_layout_equals_oracle
     from test_gpu_partitioner import EDGE_CASES
-    for i, name in enumerate(sorted(EDGE_CASES)):
-        text, ci, n = EDGE_CASES[name]
+    cases = dict(EDGE_CASES)
+    for name in ("appendix_c.json", "hand_derived_2.json"):   # the hand-derived examples as files too
+        g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
+        cases["golden " + name] = (g["instances"], g["class_index"], g["n_partitions"])
+    for i, name in enumerate(sorted(cases)):
+        text, ci, n = cases[name]
         d = tmp_path / ("c%d" % i)
         d.mkdir()
         base, ref, _ = _layout_of(text, ci, n, d)

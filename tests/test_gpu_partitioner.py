@@ -32,13 +32,23 @@ def _run(engine, text, ci, n):
     return st, got, ref
 
 
-def test_golden_known_answer(engine):
-    g = json.load(open(os.path.join(HERE, "golden", "appendix_c.json")))
+@pytest.mark.parametrize("name", ["appendix_c.json", "hand_derived_2.json"])
+def test_golden_known_answer(engine, name):
+    """The hand-derived examples (worked out from the reference's rules, not by running anything) against the GPU
+    itself, not only through the oracle."""
+    g = json.load(open(os.path.join(HERE, "golden", name)))
     st, got, ref = _run(engine, g["instances"], g["class_index"], g["n_partitions"])
     assert [set(p) for p in got["parts"]] == [{tuple(t) for t in p} for p in g["parts"]]
-    assert set(got["node_index"]) == {tuple(x) for x in g["node_index"]}
+    assert all(len(p) == len(set(p)) for p in got["parts"])
+    assert set(got["node_index"]) == {tuple(x) for x in g["node_index"]} and len(got["node_index"]) == len(g["node_index"])
     assert {k[0] + "/" + k[1]: sorted(v) for k, v in got["vp"].items()} == {k: sorted(tuple(x) for x in v) for k, v in g["vp"].items()}
     assert got["vertices"] == [v[1] for v in g["vertices"]]
+    assert got["edges"] == {tuple(e) for e in g["edges"]}
+    assert got["statistics"] == set(g["statistics"]) and got["partition_stat"] == g["partition_stat"]
+    assert {p: {u: set(s) for u, s in d.items()} for p, d in got["vp_index"].items()} == {p: {u: set(s) for u, s in d.items()} for p, d in g["vp_index"].items()}
+    if "schema_cc" in g:
+        assert got["schema_cc"] == {tuple(k): (rows, dist) for k, rows, dist in g["schema_cc"]}
+        assert got["schema_node_freq"] == g["schema_node_freq"] and got["schema_node_count"] == g["schema_node_count"]
 
 
 def test_lubm1(engine, lubm1):
