@@ -470,7 +470,7 @@ constexpr uint32_t kSlotsPerTile = 512;  // 64 bytes per record on average insid
 // Record starts among the 16 bytes of a chunk (see k_line_scan for the rule): `tin` / `lin` are the terminator / LF
 // flags of the word before the chunk. Empty lines are reported through err.
 __device__ __forceinline__ uint32_t chunk_starts(const uint32_t (&w)[4], uint32_t tin, uint32_t lin, uint32_t keep, uint64_t i0,
-                                                 unsigned long long* __restrict__ err) {
+                                                 unsigned long long* __restrict__ err, uint32_t& not_plain) {
   uint32_t L[4], R[4], T[4], H[4], S[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -479,14 +479,19 @@ __device__ __forceinline__ uint32_t chunk_starts(const uint32_t (&w)[4], uint32_
     H[d] = eq_mask(w[d], 0x23232323u);
     T[d] = L[d] | R[d];
   }
-  uint32_t tp = tin, pair = 0;
+  uint32_t tp = tin, pair = 0, hash_after = 0;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const uint32_t Tp = __builtin_amdgcn_alignbit(T[d], tp, 24);
     S[d] = Tp & ~(T[d] | H[d]);
     pair |= Tp & T[d];
+    hash_after |= Tp & H[d];
     tp = T[d];
   }
+  // anything but lines that one LF ends and a record follows: a CR, a VT or FF (bytes 0x0B / 0x0C are no terminators but
+  // sit in the same range), a comment line, two terminators in a row
+  not_plain = R[0] | R[1] | R[2] | R[3] | pair | hash_after | (tin & ~lin) |
+              ((eol_candidates(w[0]) ^ L[0]) | (eol_candidates(w[1]) ^ L[1]) | (eol_candidates(w[2]) ^ L[2]) | (eol_candidates(w[3]) ^ L[3]));
   const uint32_t m16 = (flags_to_nibble(S[0]) | (flags_to_nibble(S[1]) << 4) | (flags_to_nibble(S[2]) << 8) | (flags_to_nibble(S[3]) << 12)) & keep;
   if (pair) {
     uint32_t E[4];
@@ -522,6 +527,9 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
   uint32_t* const table = fold_lds + 3 * TK_ROUND; // earliest occurrence per bucket; afterwards the leaders' ranks (16 bits each)
   __shared__ uint16_t starts[TK_ROUND];
   __shared__ uint32_t scan_lds[8];
+  // fused form: every line of the tile ends in one LF and is followed by a record (no CR, VT, FF, comment or empty line):
+  // a record then ends right before the next one starts, and its end need not be searched for
+  __shared__ uint32_t plain_tile;
   const uint64_t tile0 = (uint64_t)blockIdx.x * LS_TILE;
   uint32_t first_rec, n_here;
   if constexpr (FUSED) {
@@ -563,16 +571,15 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       const uint32_t c = q * TK_THREADS + threadIdx.x;
       const uint32_t off = TK_PRE + c * 16;  // window offset of the chunk
       const uint4 v = *reinterpret_cast<const uint4*>(&win[off >> 2]);
-      const uint32_t before = win[(off >> 2) - 1];
-      const uint32_t cand = eol_candidates(v.x) | eol_candidates(v.y) | eol_candidates(v.z) | eol_candidates(v.w) |
-                            (eol_candidates(before) & 0x80000000u);
+      const uint32_t before = win[(off >> 2) - 1] | 0x00FFFFFFu;  // only its last byte counts
+      // "some byte below 0x0E" (exact as a yes / no for the sixteen bytes and the one before; tabs pass it too)
+      const uint32_t cand = (((v.x - 0x0E0E0E0Eu) & ~v.x) | ((v.y - 0x0E0E0E0Eu) & ~v.y) | ((v.z - 0x0E0E0E0Eu) & ~v.z) | ((v.w - 0x0E0E0E0Eu) & ~v.w) |
+                             ((before - 0x0E0E0E0Eu) & ~before)) & 0x80808080u;
       if (cand) need |= 1u << q;
       cmask[c] = 0;
     }
-    while (need) {
-      const uint32_t q = (uint32_t)__ffs((int)need) - 1;
-      need &= need - 1;
-      const uint32_t c = q * TK_THREADS + threadIdx.x;
+    if (threadIdx.x == 0) plain_tile = 1;
+    auto exact = [&](uint32_t c) -> uint32_t {
       const uint32_t off = TK_PRE + c * 16;
       const uint4 v = *reinterpret_cast<const uint4*>(&win[off >> 2]);
       const uint32_t before = win[(off >> 2) - 1];
@@ -580,8 +587,26 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
       const uint32_t lin = eq_mask(before, 0x0A0A0A0Au), tin = lin | eq_mask(before, 0x0D0D0D0Du);
       const uint32_t i = c * 16;  // tile offset
       const uint32_t keep = i + 16 <= tile_bytes ? 0xFFFFu : (i < tile_bytes ? ((1u << (tile_bytes - i)) - 1u) : 0u);
-      cmask[c] = (uint16_t)chunk_starts(w, tin, lin, keep, tile0 + i, err);
+      uint32_t not_plain;
+      cmask[c] = (uint16_t)chunk_starts(w, tin & 0x80000000u, lin & 0x80000000u, keep, tile0 + i, err, not_plain);
+      return not_plain;
+    };
+    // The chunks that passed are listed and then worked through by all threads side by side: a tile of ordinary lines
+    // has some two hundred of them, a tenth of its chunks, but the lane with the most has three, and a wave would
+    // take as many turns as that lane.
+    uint16_t* const list = cmask + LS_TILE / 16;  // what is left of the folding tables' space behind the masks
+    constexpr uint32_t kListMax = (sizeof(fold_lds) - (LS_TILE / 16) * 2) / 2;
+    uint32_t listed;
+    uint32_t at = block_excl_scan_256<uint32_t>((uint32_t)__popc(need), scan_lds, listed);
+    uint32_t odd_bytes = 0;
+    if (listed <= kListMax) {  // block-uniform
+      for (uint32_t m = need; m; m &= m - 1) list[at++] = (uint16_t)(((uint32_t)__ffs((int)m) - 1) * TK_THREADS + threadIdx.x);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < listed; i += TK_THREADS) odd_bytes |= exact(list[i]);
+    } else {
+      for (uint32_t m = need; m; m &= m - 1) odd_bytes |= exact(((uint32_t)__ffs((int)m) - 1) * TK_THREADS + threadIdx.x);
     }
+    if (odd_bytes) plain_tile = 0;
     __syncthreads();
     const uint4 mv = *reinterpret_cast<const uint4*>(cmask + threadIdx.x * (LS_PER_THREAD / 16));
     smask[0] = mv.x; smask[1] = mv.y; smask[2] = mv.z; smask[3] = mv.w;
@@ -667,7 +692,16 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
         odd |= (lds_byte(win, p) <= 0x20) && !is_eol(lds_byte(win, p));  // an empty object is fine
       }
       b[2] = p;
-      {  // end of line: first LF / CR at or after the object's first byte, four words per round
+      bool end_known = false;
+      if constexpr (FUSED) {
+        // In a tile of plain lines the record ends at the LF right before the next record's start (which this block has
+        // found itself); only the tile's last record, whose line ends beyond the tile, is searched as below.
+        if (plain_tile && threadIdx.x + 1 < (uint32_t)TK_ROUND && lr + 1 < n_here) {
+          e[2] = (uint32_t)starts[threadIdx.x + 1] - 1;
+          end_known = true;
+        }
+      }
+      if (!end_known) {  // end of line: first LF / CR at or after the object's first byte, four words per round
         uint32_t i = p >> 2;
         const uint32_t sh = p & 3;
         uint32_t lo = win[i];

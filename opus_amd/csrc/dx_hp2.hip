@@ -69,6 +69,20 @@ using ConstArgs = ConstArgsT<kConstBytes, kMaxConsts>;
 
 __device__ __forceinline__ uint64_t hash_key(int64_t a) { return mix64((uint64_t)a * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull); }
 __device__ __forceinline__ uint64_t hash_key2(int64_t a, int64_t b) { return mix64(hash_key(a) ^ ((uint64_t)b * 0xC2B2AE3D27D4EB4Full)); }
+// Where a key's chain begins in a join's table of heads. Term ids follow the order of first appearance in the text, the
+// tables are sorted by subject, and what belongs together was written together: the rows a wave probes with, and the
+// rows of the intermediate they meet, carry ids that lie close to each other. So the low `near` bits of the (first) key
+// are kept as they are and only the bits above them are mixed: keys inside one block of 2^near ids take neighbouring
+// heads (a wave's 64 probes touch a handful of cache lines instead of 64), blocks are scattered over the table like
+// hashed keys, and two different keys of one block never share a head. near = 0 mixes everything.
+__device__ __forceinline__ uint32_t head_of(int64_t a, int near) {
+  const uint64_t lo = (uint64_t)a & ((1ull << near) - 1);
+  return (uint32_t)((hash_key(a >> near) << near) | lo);
+}
+__device__ __forceinline__ uint32_t head_of2(int64_t a, int64_t b, int near, int near_b) {
+  const uint64_t lo = (uint64_t)a & ((1ull << near) - 1);
+  return (uint32_t)((hash_key2(a >> near, b >> near_b) << near) | lo);
+}
 
 // Constants -> term ids, on the device, so the host never waits for them. One wave per constant:
 // lane 0 walks the probe chain, then all lanes compare the bytes eight at a time. Returns the id in every lane.
@@ -384,13 +398,14 @@ struct BuildArgs {
   uint32_t* heads;
   uint32_t* next;
   uint32_t hmask;
+  int near, near_b;
 };
 __global__ void __launch_bounds__(256) k_build(BuildArgs b) {
   const uint32_t n = rel_rows(b.I);
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
     const int64_t k0 = b.I.col[b.key_col[0]][r];
-    const uint64_t h = b.nkey == 2 ? hash_key2(k0, b.I.col[b.key_col[1]][r]) : hash_key(k0);
-    b.next[r] = atomicExch(&b.heads[(uint32_t)h & b.hmask], r);
+    const uint32_t h = b.nkey == 2 ? head_of2(k0, b.I.col[b.key_col[1]][r], b.near, b.near_b) : head_of(k0, b.near);
+    b.next[r] = atomicExch(&b.heads[h & b.hmask], r);
   }
 }
 
@@ -401,6 +416,7 @@ struct ProbeArgs {
   const uint32_t* heads;
   const uint32_t* next;
   uint32_t hmask;
+  int near, near_b; // see head_of
   int nkey;
   int key_src[2];   // position in the arm's tuple
   int key_col[2];   // column of the intermediate
@@ -449,8 +465,8 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
       const int64_t k0 = p.I.col[p.key_col[0]][r], k1 = p.nkey == 2 ? p.I.col[p.key_col[1]][r] : 0;
       lds_k0[r] = k0;
       lds_k1[r] = k1;
-      const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
-      lds_next[r] = (uint16_t)atomicExch(&lds_heads[(uint32_t)h & (kLdsHeads - 1)], r);  // kNil's low half marks the end
+      const uint32_t h = p.nkey == 2 ? head_of2(k0, k1, p.near, p.near_b) : head_of(k0, p.near);
+      lds_next[r] = (uint16_t)atomicExch(&lds_heads[h & (kLdsHeads - 1)], r);  // kNil's low half marks the end
     }
     __syncthreads();
   }
@@ -477,8 +493,8 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
           head[j] = nI ? 0u : kNil;
         } else {
           const int64_t k0 = pick3(v[j], p.key_src[0]), k1 = p.nkey == 2 ? pick3(v[j], p.key_src[1]) : 0;
-          const uint64_t h = p.nkey == 2 ? hash_key2(k0, k1) : hash_key(k0);
-          head[j] = kLds ? lds_heads[(uint32_t)h & (kLdsHeads - 1)] : p.heads[(uint32_t)h & p.hmask];
+          const uint32_t h = p.nkey == 2 ? head_of2(k0, k1, p.near, p.near_b) : head_of(k0, p.near);
+          head[j] = kLds ? lds_heads[h & (kLdsHeads - 1)] : p.heads[h & p.hmask];
         }
       }
     }
@@ -523,6 +539,17 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
     return;
   }
   stmt_epilogue(ep);
+}
+
+// DX_JOIN_NEAR_BITS: how many low bits of a join key choose the head inside a block of neighbouring heads (0: none)
+static int join_near_bits() {
+  static const int bits = [] { const char* e = getenv("DX_JOIN_NEAR_BITS"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : v > 16 ? 16 : v; }();
+  return bits;
+}
+
+static int join_near_b_bits() {
+  static const int bits = [] { const char* e = getenv("DX_JOIN_NEAR_B"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > 16 ? 16 : v; }();
+  return bits;
 }
 
 // ---- planning ----------------------------------------------------------------------------------------
@@ -1047,7 +1074,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           uint32_t* next = tmp32.back().p;
           BuildArgs ba{};
           ba.I = I; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
-          ba.heads = nullptr; ba.next = next; ba.hmask = hsize - 1;
+          ba.heads = nullptr; ba.next = next; ba.hmask = hsize - 1; ba.near = join_near_bits(); ba.near_b = join_near_b_bits();
           const uint32_t icap = I.cap;
           const uint64_t off_words = my_heads_off;
           DevBuf<uint32_t>* arena = &heads_arena;
@@ -1055,7 +1082,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
             ba.heads = arena->p + off_words;
             hipLaunchKernelGGL(k_build, dim3(scan_grid(icap)), dim3(256), 0, s, ba);
           });
-          pa.next = next; pa.hmask = hsize - 1;
+          pa.next = next; pa.hmask = hsize - 1; pa.near = join_near_bits(); pa.near_b = join_near_b_bits();
         }
         pa.count_only = count_only ? 1 : 0;
         pa.out_count = cnt;
@@ -1709,9 +1736,9 @@ dx_result* run_query_sharded(dx_ctx* ctx, const std::string& sql, int mode) {
           DX_HIP(hipMemsetAsync(heads, 0xFF, (size_t)hsize * 4, s));
           BuildArgs ba{};
           ba.I = Id; ba.nkey = pa.nkey; ba.key_col[0] = pa.key_col[0]; ba.key_col[1] = pa.key_col[1];
-          ba.heads = heads; ba.next = next; ba.hmask = hsize - 1;
+          ba.heads = heads; ba.next = next; ba.hmask = hsize - 1; ba.near = join_near_bits(); ba.near_b = join_near_b_bits();
           if (I.rows) hipLaunchKernelGGL(k_build, dim3(scan_grid(I.rows)), dim3(256), 0, s, ba);
-          pa.heads = heads; pa.next = next; pa.hmask = hsize - 1;
+          pa.heads = heads; pa.next = next; pa.hmask = hsize - 1; pa.near = join_near_bits(); pa.near_b = join_near_b_bits();
         }
         ArmDev ad{};
         ad.rows = (uint32_t)A2.rows;
