@@ -314,6 +314,165 @@ def sharded_query_leg(args, eng0, plans, qnames, want_counts, rank, world, local
     return out
 
 
+def hetero_leg(args):
+    """`--workload swdf|dbpedia`: the heterogeneous-schema configurations of BASELINE.json (configs[3], configs[4]) on one
+    GPU: a synthetic data set of that shape (many small vertical partitions / thousands of predicates with skew), the
+    partitioner timed as in the default run, then the query shapes of the reference's SWDF and DBpedia folders
+    (tests/golden/query_shapes.json: no constants of the real data sets, only the patterns) instantiated over the data
+    and run warm, with the cost of loading the many small tables a statement names reported per table."""
+    import random
+
+    import torch
+    from opus_amd.engine import DX_QUERY_COUNT, DxError, Engine
+    from opus_amd.host import translator as T
+    from opus_amd.workloads import hetero
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shape_queries as SQ
+    from oracle import dap_oracle  # only parses the sample lines and names directories (the checker's helpers, nothing timed)
+
+    shape = args.workload
+    n_triples = args.triples or 12_000_000
+    text, ci, k, sample = hetero.generate_large(shape, n_triples, seed=0, n_partitions=args.partitions)
+    n_bytes = int(text.size)
+    dev = torch.from_numpy(text).cuda()
+    del text
+    torch.cuda.synchronize()
+    eng = Engine(0)
+    eng.partition_device(dev.data_ptr(), n_bytes, ci, k)
+    for _ in range(args.warmup):
+        eng.partition_device(dev.data_ptr(), n_bytes, ci, k)
+    part_s, stage_ms = [], []
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        st = eng.partition_device(dev.data_ptr(), n_bytes, ci, k)
+        part_s.append(time.perf_counter() - t0)
+        stage_ms.append([st.ms_stage[i] for i in range(12)])
+    elapsed = time.perf_counter() - t_begin
+    stage_names = [eng.lib.dx_part_stage_name(i).decode() for i in range(12)]
+    stage_avg = {stage_names[i]: float(np.mean([x[i] for x in stage_ms])) for i in range(12) if stage_names[i]}
+    tables = [t for t in eng.tables() if t["in_layout"]]
+    rows_by_part = {}
+    for t in tables:
+        rows_by_part["%05d" % t["partition"]] = rows_by_part.get("%05d" % t["partition"], 0) + t["rows"]
+    per_part = {}
+    for t in tables:
+        per_part[t["partition"]] = per_part.get(t["partition"], 0) + 1
+
+    # ---- the query shapes, instantiated over the first lines of the text (what matches there matches in the whole)
+    index = SQ.TripleIndex(dap_oracle.parse_instances(sample))
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "query_shapes.json")))
+    rng = random.Random(5)
+    sparqls = []
+    for folder, lst in shapes.items():
+        for i, sh in enumerate(lst):
+            bind = SQ.instantiate(sh["patterns"], index, rng)
+            if bind is not None:
+                sparqls.append(("%s/%d" % (folder, i), sh["patterns"], SQ.sparql(sh["patterns"], bind), bind))
+    consts = sorted({v for _, _, _, b in sparqls for key, v in b.items() if key[0] == "C"})
+    ids = eng.lookup(consts)
+    id_of = {c: int(i) for c, i in zip(consts, ids) if i >= 0}
+    u, t = eng.node_index()
+    sel = np.isin(u, np.fromiter(id_of.values(), dtype=np.int64, count=len(id_of))) if id_of else np.zeros(len(u), bool)
+    tvals = np.unique(t[sel])
+    tmap = dict(zip(tvals.tolist(), eng.decode(tvals))) if tvals.size else {}
+    name_of = {i: c for c, i in id_of.items()}
+    ni = {}
+    for uu, tt in zip(u[sel].tolist(), t[sel].tolist()):
+        ni.setdefault(name_of[uu], []).append(tmap[tt])
+    vpi_cache = {}
+
+    def sub_parts(part, uri):  # the VP index rows of one uri in one partition: "s<dir>" / "o<dir>"
+        q = int(part)
+        if q not in vpi_cache:
+            vpi_cache[q] = eng.vp_index(q)
+        vu, vr, vp = vpi_cache[q]
+        i = id_of.get(uri, -1)
+        m = vu == i
+        if not m.any():
+            return []
+        preds = eng.decode(vp[m])
+        return sorted({("s" if r == 0 else "o") + dap_oracle.uri_to_storage(pp) for r, pp in zip(vr[m].tolist(), preds)})
+
+    cidx = T.load_class_index(ci)
+    times, dev_ms, load_us, counts, tables_named = {}, {}, [], {}, []
+    skipped = {"not_indexable": 0, "unsupported_template": 0, "no_directory": 0}
+    first = True
+    for name, patterns, q, _ in sparqls:
+        try:
+            tr = T.translate_query(name, q, lambda x: ni.get(x, []), cidx, rows_by_part, sub_parts)
+        except NotImplementedError:
+            skipped["unsupported_template"] += 1
+            continue
+        if tr is None:
+            skipped["not_indexable"] += 1
+            continue
+        sql, parts = parse_translated(tr)
+        eng.unload_all()
+        try:
+            t0 = time.perf_counter()
+            eng.load_tables(parts)
+            t_load = time.perf_counter() - t0
+        except DxError:
+            skipped["no_directory"] += 1
+            continue
+        load_us.append((len(parts), t_load * 1e6))
+        try:
+            if first:
+                eng.query(sql, DX_QUERY_COUNT).close()
+                first = False
+            eng.query(sql, DX_QUERY_COUNT).close()   # a statement's first run sizes its buffers (and may run twice for that)
+        except DxError as ex:
+            if ex.code != -95:
+                raise
+            skipped["beyond_an_engine_limit"] = skipped.get("beyond_an_engine_limit", 0) + 1
+            continue
+        t0 = time.perf_counter()
+        r = eng.query(sql, DX_QUERY_COUNT)
+        times[name] = (time.perf_counter() - t0) * 1e3
+        dev_ms[name] = r.device_ms
+        counts[name] = int(r.count)
+        tables_named.append(len(parts))
+        r.close()
+    geo = lambda d: math.exp(sum(math.log(max(v, 1e-9)) for v in d.values()) / max(1, len(d)))  # noqa: E731
+    n_rec, n_ent = st.n_triples, int(st.n_dict_entries)
+    tok_bytes = n_bytes + 13 * n_rec + 16 * n_ent
+    out = {
+        "metric": "LUBM Q1-Q14 geo-mean query ms + DAP partitioning triples/sec",
+        "value": st.n_triples * args.steps / sum(part_s), "unit": "triples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": "%s-shaped synthetic data (%d triples, %.2f GB of N-Triples text, %d predicates, %d classes), %d first-level "
+                               "partitions; query shapes of the reference's swdf / dbpedia folders instantiated over it"
+                               % (shape.upper(), st.n_triples, n_bytes / 1e9, int(st.n_predicates), hetero.SHAPES[shape].n_class, k),
+                   "parallelism": "single GPU"},
+        "value_basis": "triples / partitioner wall time (a step = 1 partitioner call); the queries run after the timed steps",
+        "partition_ms": float(np.median(part_s)) * 1e3, "partition_stage_ms": stage_avg,
+        "terms": int(st.n_terms), "replication_factor": st.n_rows / max(1, st.n_triples),
+        "vp_tables": len(tables), "vp_tables_per_partition": {"min": min(per_part.values()), "max": max(per_part.values())},
+        "median_rows_per_table": float(np.median([t["rows"] for t in tables])),
+        "queries_run": len(times), "queries_with_answers": sum(1 for c in counts.values() if c > 0), "queries_skipped": skipped,
+        "query_geomean_ms": geo(times), "query_geomean_device_ms": geo(dev_ms),
+        "tables_named_per_query": {"median": float(np.median(tables_named)), "max": int(max(tables_named))} if tables_named else None,
+        "load_tables": {"calls": len(load_us), "tables": int(sum(n for n, _ in load_us)),
+                        "us_per_table": float(sum(t for _, t in load_us) / max(1, sum(n for n, _ in load_us))),
+                        "worst_call": {"tables": int(max(load_us, key=lambda x: x[1])[0]), "us": float(max(load_us, key=lambda x: x[1])[1])} if load_us else None},
+        "roofline": {"bound": "hbm", "kernel": "k_tokenise", "ms": stage_avg["tokenise_hash"], "algorithmic_bytes": tok_bytes,
+                     "achieved": tok_bytes / (stage_avg["tokenise_hash"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": tok_bytes / (stage_avg["tokenise_hash"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import cpu_port
+        n_sample = min(n_bytes, 300 << 20)   # a bounded piece of the same text: about 2.5 M triples, 10-20 s on one core
+        host = dev[:n_sample].cpu().numpy()
+        cut = int(np.flatnonzero(host == 10)[-1]) + 1
+        one = cpu_port.run(host[:cut], ci, k)
+        out["cpu_baseline"] = {"value": one["n_triples"] / one["seconds"], "unit": "triples/s", "cores": 1, "kind": "port",
+                               "sample": "oracle/cpu_port.cpp, partitioner only, on the first %d triples of the same text in %.1f s" % (one["n_triples"], one["seconds"])}
+    print(json.dumps(out))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,7 +495,14 @@ def main():
                     help="communicator of the sharded run: the library's own over librccl, or torch.distributed through callbacks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--workload", default="lubm", choices=["lubm", "swdf", "dbpedia"],
+                    help="lubm: the headline run. swdf / dbpedia: heterogeneous-schema data of that shape on one GPU (see hetero_leg)")
+    ap.add_argument("--triples", type=int, default=0, help="--workload swdf|dbpedia: triples to generate (default 12 million)")
     args = ap.parse_args()
+    if args.workload != "lubm":
+        if args.gpus != 1:
+            raise SystemExit("--workload %s runs on one GPU" % args.workload)
+        return hetero_leg(args)
 
     import torch
     import torch.distributed as dist
@@ -479,6 +645,14 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # Only these three kernels have a timer of their own; every other kernel is part of a stage. No stage's time
+        # outside them may exceed the dominant kernel's, or one of its kernels might be the longer one (checked from all
+        # stage timers of the same steps; the dictionary stage holds the table clear and the claims).
+        residual = dict(stage_avg)
+        residual["dictionary"] = stage_avg["dictionary"] - stage_avg["dict_clear_kernel"] - stage_avg["dict_claim_kernel"]
+        for name in ("tokenise_hash", "dict_clear_kernel", "dict_claim_kernel"):
+            residual.pop(name, None)
+        longer = {k: v for k, v in residual.items() if v > dom_ms}
         # HBM-side bytes per launch of that kernel from the PMC passes kept under profiles/ (same command,
         # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; see profiles/summarise.py); null when the
         # workload is not the profiled one
@@ -524,7 +698,8 @@ def main():
             "query_counts": {n: int(counts[n]) for n in qnames},
             "roofline": {"bound": "hbm", "kernel": dom, "ms": dom_ms, "algorithmic_bytes": dom_bytes,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic},
+                         "traffic": traffic,
+                         "stages_that_could_hold_a_longer_kernel": longer or None},
             "kernel_GBps": {k: v[1] / (v[0] * 1e-3) / 1e9 for k, v in kernels.items()},
         }
         if load_rows:

@@ -1133,15 +1133,23 @@ static CatalogTable& register_table(dx_ctx* ctx, const char* partition_key) {
       t.key = key;
       t.view = view;
       bool resident = false;
-      const PartitionState& ps = ctx->part;
+      PartitionState& ps = ctx->part;
       if (ps.valid) {
-        const size_t dash = key.find('-');
-        const std::string pn = key.substr(0, dash), sub = dash == std::string::npos ? "" : key.substr(dash + 1);
-        for (const VpTable& vt : ps.tables) {
-          if (!vt.in_layout || part_name(vt.partition) != pn || "_3=" + ps.pred_storage[vt.pidx] != sub) continue;
-          t.slices.push_back({ps.row_s.p + vt.begin, ps.row_o.p + vt.begin, vt.rows});
-          resident = true;
+        if (!ps.by_key_built) {
+          ps.by_key.reserve(ps.tables.size());
+          std::vector<std::string> pn;  // partition numbers as the keys spell them
+          for (int q = 0; q < ps.n_partitions; ++q) pn.push_back(part_name(q) + "-_3=");
+          for (uint32_t i = 0; i < ps.tables.size(); ++i)
+            if (ps.tables[i].in_layout) ps.by_key[pn[ps.tables[i].partition] + ps.pred_storage[ps.tables[i].pidx]].push_back(i);
+          ps.by_key_built = true;
         }
+        auto found = ps.by_key.find(key);
+        if (found != ps.by_key.end())
+          for (uint32_t i : found->second) {
+            const VpTable& vt = ps.tables[i];
+            t.slices.push_back({ps.row_s.p + vt.begin, ps.row_o.p + vt.begin, vt.rows});
+            resident = true;
+          }
       }
       if (!resident) {
         auto im = ctx->imported.find(key);

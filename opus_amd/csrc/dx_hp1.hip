@@ -2073,21 +2073,75 @@ k_count_marked(const uint8_t* __restrict__ seen, uint64_t n_padded /*multiple of
   if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);  // few blocks: the counter is one word in one L2 channel
 }
 
+// Small tables, all in one launch, one block each: the distinct values of a column are counted in a set in LDS (open
+// addressing over 32-bit ids), a sorted subject column by its changes. A heterogeneous schema has tens of thousands of
+// tables of a few dozen rows, and a statement with a variable predicate names hundreds of them: three launches and a
+// pass over a byte per dictionary term for each of them was milliseconds per statement.
+constexpr uint32_t kSmallStatsRows = 16384, kSmallStatsSlots = 32768;
+struct SmallTable { const int64_t* s; const int64_t* o; uint32_t rows, sorted_s; };
+__global__ void __launch_bounds__(256) k_stats_small(const SmallTable* __restrict__ tabs, const uint32_t* __restrict__ where, unsigned long long* __restrict__ out) {
+  __shared__ uint32_t set[kSmallStatsSlots];
+  __shared__ uint32_t lds[8];
+  const SmallTable t = tabs[blockIdx.x];
+  for (int col = 1; col >= 0; --col) {
+    const int64_t* __restrict__ v = col ? t.o : t.s;
+    uint32_t c = 0;
+    if (col == 0 && t.sorted_s) {
+      for (uint32_t i = threadIdx.x; i < t.rows; i += 256) c += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+    } else {
+      for (uint32_t i = threadIdx.x; i < kSmallStatsSlots; i += 256) set[i] = 0xFFFFFFFFu;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < t.rows; i += 256) {
+        const uint32_t x = (uint32_t)v[i];  // term ids are below 2^32 - 1
+        uint32_t h = (uint32_t)mix64(x) & (kSmallStatsSlots - 1);
+        for (;;) {
+          const uint32_t old = atomicCAS(&set[h], 0xFFFFFFFFu, x);
+          if (old == 0xFFFFFFFFu) { ++c; break; }
+          if (old == x) break;
+          h = (h + 1) & (kSmallStatsSlots - 1);
+        }
+      }
+    }
+    uint32_t total;
+    (void)block_excl_scan_256<uint32_t>(c, lds, total);  // its barriers also end the use of the set
+    if (threadIdx.x == 0) out[2 * where[blockIdx.x] + col] = total;
+  }
+}
+
 void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
   hipStream_t s = ctx->stream;
   std::vector<CatalogTable*> todo;
-  for (CatalogTable* t : tables)
-    if (t->stats_pending && std::find(todo.begin(), todo.end(), t) == todo.end()) todo.push_back(t);
+  {
+    std::unordered_map<CatalogTable*, bool> seen_tables;
+    for (CatalogTable* t : tables)
+      if (t->stats_pending && seen_tables.emplace(t, true).second) todo.push_back(t);
+  }
   if (todo.empty()) return;
   if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
   const uint64_t n_terms = ctx->dict.n_terms;
   DevBuf<unsigned long long> cnt(ctx->pool, 2 * todo.size());
   DX_HIP(hipMemsetAsync(cnt.p, 0, 16 * todo.size(), s));
-  const uint64_t n_padded = (n_terms + 15) / 16 * 16 + 16;
-  DevBuf<uint8_t> seen(ctx->pool, n_padded);  // one map for all: the stream runs the tables one after another
+  std::vector<SmallTable> small;
+  std::vector<uint32_t> small_where;
   for (size_t k = 0; k < todo.size(); ++k) {
     const CatalogTable& t = *todo[k];
-    if (t.rows == 0) continue;
+    if (t.rows == 0 || t.rows > kSmallStatsRows) continue;
+    small.push_back({t.s, t.o, (uint32_t)t.rows, t.slices.size() == 1 ? 1u : 0u});
+    small_where.push_back((uint32_t)k);
+  }
+  DevBuf<SmallTable> d_small(ctx->pool, small.size());
+  DevBuf<uint32_t> d_where(ctx->pool, small.size());
+  if (!small.empty()) {
+    DX_HIP(hipMemcpyAsync(d_small.p, small.data(), small.size() * sizeof(SmallTable), hipMemcpyHostToDevice, s));
+    DX_HIP(hipMemcpyAsync(d_where.p, small_where.data(), small.size() * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_stats_small, dim3((unsigned)small.size()), dim3(256), 0, s, d_small.p, d_where.p, cnt.p);
+  }
+  const uint64_t n_padded = (n_terms + 15) / 16 * 16 + 16;
+  DevBuf<uint8_t> seen;  // one map for all large tables: the stream runs them one after another
+  for (size_t k = 0; k < todo.size(); ++k) {
+    const CatalogTable& t = *todo[k];
+    if (t.rows <= kSmallStatsRows) continue;
+    if (!seen.p) seen = DevBuf<uint8_t>(ctx->pool, n_padded);
     // grids of a few hundred blocks: every block ends with one atomic on the same counter
     const unsigned g = (unsigned)std::min<uint64_t>(256, (t.rows + 255) / 256);
     const bool sorted_s = t.slices.size() == 1;  // one slice of a partition: rows are in (s, o) order

@@ -589,17 +589,21 @@ int find_root(std::vector<int>& uf, int x) { while (uf[x] != x) x = uf[x] = uf[u
 Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true, uint64_t text_hash = 0) {
   Plan plan;
   const long long kLookup = (-0x7FFFFFFFFFFFFFFFll - 1);
-  auto add_const = [&](const std::string& s, bool is_virtual) -> int {
+  // constants a filter compares with: looked up in the dictionary on the device (at most kMaxConsts distinct ones)
+  auto add_const = [&](const std::string& s) -> int {
     for (size_t i = 0; i < plan.const_str.size(); ++i)
-      if (plan.const_str[i] == s && (plan.const_preset[i] != kLookup) == is_virtual) return (int)i;
-    long long preset = kLookup;
-    if (is_virtual) {
-      plan.virtual_terms.push_back(s);
-      preset = -(long long)(2 + plan.virtual_terms.size() - 1);
-    }
+      if (plan.const_str[i] == s) return (int)i;
     plan.const_str.push_back(s);
-    plan.const_preset.push_back(preset);
+    plan.const_preset.push_back(kLookup);
     return (int)plan.const_str.size() - 1;
+  };
+  // constants an arm projects ('<partition-_3=predicate>' AS P in every arm of a variable-predicate UNION): never
+  // looked up, they carry ids of their own, -(2 + index), and there may be as many as there are arms
+  auto add_virtual = [&](const std::string& s) -> long long {
+    for (size_t i = 0; i < plan.virtual_terms.size(); ++i)
+      if (plan.virtual_terms[i] == s) return -(long long)(2 + i);
+    plan.virtual_terms.push_back(s);
+    return -(long long)(2 + plan.virtual_terms.size() - 1);
   };
   // variable classes: union-find over (sub, column)
   std::vector<std::pair<int, int>> slots;
@@ -687,11 +691,11 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true, uint64_
       if (sub.arms.size() > 1 && !may_allocate && it->second.several_sources && it->second.rows >= 2 && !it->second.distinct_view)
         throw DxError(DX_E_INVAL, "table " + it->second.view + " has no duplicate-free copy yet: run the statement through dx_query once");
       a.t = sub.arms.size() > 1 ? distinct_view_of(ctx, it->second) : &it->second;
-      if (arm.has_s) a.fs = add_const(arm.s_const, false);
-      if (arm.has_o) a.fo = add_const(arm.o_const, false);
+      if (arm.has_s) a.fs = add_const(arm.s_const);
+      if (arm.has_o) a.fo = add_const(arm.o_const);
       for (int c = 0; c < r.ncols; ++c) {
         a.src[c] = arm.proj[c].src;
-        if (a.src[c] == 2) { a.src_ci[c] = add_const(arm.proj[c].constant, true); a.src_val[c] = plan.const_preset[a.src_ci[c]]; }
+        if (a.src[c] == 2) { a.src_ci[c] = -1; a.src_val[c] = add_virtual(arm.proj[c].constant); }
       }
       r.arms.push_back(a);
       r.rows_upper += a.t->rows;

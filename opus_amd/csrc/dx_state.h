@@ -54,6 +54,10 @@ struct PartitionState {
   std::vector<int64_t> pred_terms;    // pidx -> term id
   std::vector<std::string> pred_strings, pred_storage;  // pidx -> IRI text, sanitised directory name
   std::vector<VpTable> tables;        // non-empty ones, ordered by (partition, pidx)
+  // "PPPPP-_3=<directory>" -> the tables behind that key (several when predicates share a directory), made when a table
+  // is first asked for by key: a schema of ten thousand predicates has eighty thousand tables, and a statement names hundreds
+  std::unordered_map<std::string, std::vector<uint32_t>> by_key;
+  bool by_key_built = false;
   // node index
   DevBuf<int64_t> node_s, node_o;
   uint64_t n_node = 0;

@@ -236,3 +236,44 @@ def test_union_over_a_directory_shared_by_two_predicates():
         r.close()
     finally:
         e.close()
+
+
+def test_table_statistics_of_small_and_large_tables():
+    """The distinct subjects / objects the join-order search works with: counted in one launch for all small tables (a set
+    in LDS per table), by marking terms for large ones; both against numpy over the tables' own rows. Tables whose
+    predicates share a directory are concatenations and go through the set for both columns."""
+    from opus_amd import lubm
+    from opus_amd.engine import Engine
+    from opus_amd.workloads import hetero
+    from oracle import dap_oracle
+    e = Engine(0)
+    try:
+        text, ci, k = hetero.generate("swdf", 30000, seed=4)
+        e.partition_text(text.encode(), ci, k)
+        strs = e.decode(np.arange(e.term_count(), dtype=np.int64))
+        by_key = {}
+        for t in e.tables():
+            if t["in_layout"]:
+                s, o = e.table_rows(t["index"], t["rows"])
+                key = "%s-_3=%s" % (dap_oracle.partition_name(t["partition"]), dap_oracle.uri_to_storage(strs[t["predicate"]]))
+                by_key.setdefault(key, []).append((s, o))
+        assert any(len(v) > 1 for v in by_key.values())   # some directories are shared
+        keys = sorted(by_key)
+        e.load_tables(keys)
+        for key in keys:
+            s = np.concatenate([a for a, _ in by_key[key]])
+            o = np.concatenate([b for _, b in by_key[key]])
+            assert e.table_stats(key) == [len(s), len(np.unique(s)), len(np.unique(o))], key
+        # tables above the small-table bound: LUBM-2's larger ones
+        arr, _ = lubm.generate(0, 2, seed=2, ontology=0)
+        e.partition_text(arr, lubm.class_index_text(4, 0), 4)
+        strs = e.decode(np.arange(e.term_count(), dtype=np.int64))
+        big = [t for t in e.tables() if t["in_layout"] and t["rows"] > 16384]
+        assert big
+        for t in big[:6]:
+            s, o = e.table_rows(t["index"], t["rows"])
+            key = "%s-_3=%s" % (dap_oracle.partition_name(t["partition"]), dap_oracle.uri_to_storage(strs[t["predicate"]]))
+            e.load_table(key)
+            assert e.table_stats(key) == [len(s), len(np.unique(s)), len(np.unique(o))], key
+    finally:
+        e.close()
