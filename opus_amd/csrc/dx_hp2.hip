@@ -33,15 +33,44 @@ constexpr int MAXSTEPS = 30;
 constexpr int kConstBytes = 2560;
 constexpr int kMaxConsts = 32;
 
+// An intermediate relation. Its rows are claimed from a counter by the blocks that emit them, and the L2 carries out
+// the claims on one word one after another (about 8 ns apiece): an emitting kernel over ten thousand tiles spends a
+// hundred microseconds on that alone. A relation that is expected to be large is therefore striped: kStripes counters,
+// a block claims from the one its number picks, and stripe x owns the rows of every kStripes-th group of
+// kStripeGroup rows -- row i of stripe x lies at (i / G) * (S * G) + x * G + i % G. The relation stays one buffer with
+// the same capacity; near its end some rows are missing (the stripes do not end level), and whoever walks it by row
+// number (k_build) asks row_is_there(). Rows reached through a join's chains are there by construction.
+constexpr uint32_t kStripes = 8, kStripeGroupBits = 10, kStripeStride = 32;  // counters 256 bytes apart: a cache line and a channel each
 struct RelDev {
   int64_t* col[MAXC];
   int ncols;
   uint32_t cap;
-  const unsigned long long* count;
+  const unsigned long long* count;  // stripes > 1: the first of kStripes counters, kStripeStride words apart
+  uint32_t stripes;                 // 0 or 1: rows [0, *count)
 };
+__device__ __forceinline__ uint64_t stripe_row(uint64_t i, uint32_t x) {
+  return ((i >> kStripeGroupBits) << (kStripeGroupBits + 3)) + ((uint64_t)x << kStripeGroupBits) + (i & ((1u << kStripeGroupBits) - 1));
+}
+static_assert(kStripes == 8, "stripe_row shifts by three bits");
+// one past the last row that may be there
 __device__ __forceinline__ uint32_t rel_rows(const RelDev& r) {
-  const unsigned long long c = *r.count;
-  return c < r.cap ? (uint32_t)c : r.cap;
+  if (r.stripes <= 1) {
+    const unsigned long long c = *r.count;
+    return c < r.cap ? (uint32_t)c : r.cap;
+  }
+  unsigned long long groups = 0;
+  for (uint32_t x = 0; x < kStripes; ++x) {
+    const unsigned long long g = (r.count[x * kStripeStride] + (1u << kStripeGroupBits) - 1) >> kStripeGroupBits;
+    groups = g > groups ? g : groups;
+  }
+  const unsigned long long e = groups << (kStripeGroupBits + 3);
+  return e < r.cap ? (uint32_t)e : r.cap;
+}
+__device__ __forceinline__ bool row_is_there(const RelDev& r, uint32_t row) {
+  if (r.stripes <= 1) return true;  // the caller stays below rel_rows()
+  const uint32_t x = (row >> kStripeGroupBits) & (kStripes - 1);
+  const uint64_t i = ((uint64_t)(row >> (kStripeGroupBits + 3)) << kStripeGroupBits) | (row & ((1u << kStripeGroupBits) - 1));
+  return i < r.count[x * kStripeStride];  // (a wave that walks 64 rows from a multiple of 64 asks about one stripe)
 }
 
 struct ArmDev {
@@ -172,6 +201,9 @@ struct Epilogue {
   unsigned long long* host_counters;
   unsigned long long* host_seq;
   unsigned long long seq;
+  unsigned long long* stripe_counters;  // step k's stripe x: [x * kStripeStride + k]
+  unsigned long long* host_extent;      // per striped step: one past the last row of its relation that is in use
+  uint32_t striped;                     // bit k: step k's relation is striped (its row counter is the sum of its stripes')
 };
 
 // Values of the arm's two filter constants. In the statement's first kernel they are looked up by this block
@@ -244,6 +276,19 @@ __device__ __forceinline__ void stmt_epilogue(const Epilogue& ep, unsigned long 
   if (!last) return;
   if ((int)threadIdx.x < ep.n) {
     unsigned long long v = __hip_atomic_load(&ep.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 32 && (ep.striped >> threadIdx.x & 1)) {
+      unsigned long long most = 0;
+      v = 0;
+      for (uint32_t x = 0; x < kStripes; ++x) {
+        unsigned long long* c = &ep.stripe_counters[x * kStripeStride + threadIdx.x];
+        const unsigned long long n = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += n;
+        most = n > most ? n : most;
+      }
+      const unsigned long long groups = (most + (1u << kStripeGroupBits) - 1) >> kStripeGroupBits;
+      __hip_atomic_store(&ep.host_extent[threadIdx.x], groups << (kStripeGroupBits + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (add_to && add_to == &ep.counters[threadIdx.x]) v += total_s;  // a counter other kernels of the step have added to as well
     __hip_atomic_store(&ep.host_counters[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&ep.counters[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -345,6 +390,13 @@ __device__ __forceinline__ unsigned long long block_claim(uint32_t mine, unsigne
   __syncthreads();  // base_s is written again in the next tile
   return base;
 }
+// The counter a block claims its output rows from, and where the i-th row it was given lies.
+__device__ __forceinline__ unsigned long long* claim_counter(const RelDev& out, unsigned long long* counter) {
+  return out.stripes > 1 ? counter + (blockIdx.x & (kStripes - 1)) * kStripeStride : counter;
+}
+__device__ __forceinline__ uint64_t out_row(const RelDev& out, uint64_t i) {
+  return out.stripes > 1 ? stripe_row(i, blockIdx.x & (kStripes - 1)) : i;
+}
 
 // Filtered scan that appends the projected tuple to `out` (first relation of a plan).
 template <int kRowsPerThread>
@@ -376,16 +428,17 @@ k_scan_emit(ArmDev a, const int64_t* __restrict__ consts, RelDev out, unsigned l
       if (i < a.rows && arm_row(a, consts, want_s, want_o, i, v[j], use_pre, pre_s[j], pre_o[j])) { hits |= 1u << j; ++n; }
     }
     uint32_t before;
-    unsigned long long pos = block_claim(n, out_count, before) + before;
+    unsigned long long idx = block_claim(n, claim_counter(out, out_count), before) + before;
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j)
       if (hits & (1u << j)) {
+        const uint64_t pos = out_row(out, idx);
         if (pos < out.cap) {
 #pragma unroll
           for (int k = 0; k < 3; ++k)
             if (k < a.nsrc) out.col[k][pos] = v[j][k];
         }
-        ++pos;
+        ++idx;
       }
   }
   stmt_epilogue(ep);
@@ -403,6 +456,7 @@ struct BuildArgs {
 __global__ void __launch_bounds__(256) k_build(BuildArgs b) {
   const uint32_t n = rel_rows(b.I);
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    if (!row_is_there(b.I, r)) continue;
     const int64_t k0 = b.I.col[b.key_col[0]][r];
     const uint32_t h = b.nkey == 2 ? head_of2(k0, b.I.col[b.key_col[1]][r], b.near, b.near_b) : head_of(k0, b.near);
     b.next[r] = atomicExch(&b.heads[h & b.hmask], r);
@@ -514,7 +568,7 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
     }
     if (p.count_only) { local += n; continue; }
     uint32_t before;
-    unsigned long long pos = block_claim(n, p.out_count, before) + before;
+    unsigned long long idx = block_claim(n, claim_counter(p.out, p.out_count), before) + before;
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
       if (!nhit[j]) continue;
@@ -523,11 +577,12 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
       const bool single = p.nkey != 0 && nhit[j] == 1;
       for (uint32_t r = single ? hit[j] : head[j]; r != kNil; r = single ? kNil : (p.nkey == 0 ? (r + 1 < nI ? r + 1 : kNil) : chain_next(r))) {
         if (!single && !matches(r, k0, k1)) continue;
+        const uint64_t pos = out_row(p.out, idx);
         if (pos < p.out.cap) {
           for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
           for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = pick3(v[j], p.new_src[c]);
         }
-        ++pos;
+        ++idx;
       }
     }
   }
@@ -545,6 +600,12 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
 static int join_near_bits() {
   static const int bits = [] { const char* e = getenv("DX_JOIN_NEAR_BITS"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : v > 16 ? 16 : v; }();
   return bits;
+}
+
+// DX_JOIN_STRIPE_ROWS: a relation expected to hold at least this many rows is striped when a hash join reads it (0: never)
+static uint64_t join_stripe_rows() {
+  const char* e = getenv("DX_JOIN_STRIPE_ROWS");  // (read per statement: the tests switch it)
+  return e ? (uint64_t)strtoull(e, nullptr, 10) : 65536ull;
 }
 
 static int join_near_b_bits() {
@@ -842,11 +903,15 @@ void launch_probe(hipStream_t s, uint64_t rows, const ProbeArgs& p, const Epilog
 }  // namespace
 
 // device block of a context: row counters and tickets (see Epilogue)
-constexpr size_t kQueryCounterBytes = sizeof(unsigned long long) * (MAXSTEPS + 2 + 1 + kSubTickets);
+// ... and, from a multiple of 256 bytes on, the stripes' row counters of striped relations (see RelDev)
+constexpr size_t kStripeCountersAt = (MAXSTEPS + 2 + 1 + kSubTickets + kStripeStride - 1) / kStripeStride * kStripeStride;  // in words
+constexpr size_t kQueryCounterBytes = sizeof(unsigned long long) * (kStripeCountersAt + kStripes * kStripeStride);
+static_assert(MAXSTEPS <= (int)kStripeStride && MAXSTEPS <= 32, "a word per step between two stripes, a bit per step in Epilogue::striped");
 // Pinned host block the final counters land in.
 constexpr int kShardedWords = 2 * 64 + 8;
 struct QueryHostBlock {
   unsigned long long counters[MAXSTEPS + 2];
+  unsigned long long extent[MAXSTEPS + 2];    // striped relations: rows of the buffer in use (see Epilogue::host_extent)
   unsigned long long seq;                     // number of the statement whose counters these are (written last)
   unsigned long long sharded[kShardedWords];  // several GPUs: row counts per destination rank on their way to the host
 };
@@ -988,6 +1053,29 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
       std::vector<uint64_t> step_cap(nsteps, 0);
       unsigned long long* preset_counter = nullptr;  // fused: the first relation is a table used in place
       unsigned long long preset_value = 0;
+      // Which steps join how: known before anything is laid out, because a step's output is striped (see RelDev) only
+      // when the step that reads it is a hash join with its table in HBM.
+      std::vector<int> step_nkey(nsteps, 0);
+      std::vector<char> step_small(nsteps, 0);
+      {
+        std::vector<int> cls(plan.rels[0].cls, plan.rels[0].cls + plan.rels[0].ncols);
+        for (int k = 1; k < nsteps; ++k) {
+          const PlanRel& r = plan.rels[k];
+          for (int c = 0; c < r.ncols; ++c)
+            if (std::find(cls.begin(), cls.end(), r.cls[c]) != cls.end()) ++step_nkey[k];
+            else cls.push_back(r.cls[c]);
+          step_small[k] = fused && step_nkey[k] > 0 && !(regular_steps & (1ull << k)) && k - 1 < (int)plan.est_rows.size() &&
+                          plan.est_rows[k - 1] <= kLdsRows / 4;
+        }
+      }
+      uint32_t striped = 0;
+      unsigned long long* const stripes_p = counters_p + kStripeCountersAt;
+      auto stripe_output = [&](int k) {
+        return fused && k + 1 < nsteps && k < (int)plan.est_rows.size() && step_nkey[k + 1] > 0 && !step_small[k + 1] &&
+               join_stripe_rows() > 0 && plan.est_rows[k] >= (double)join_stripe_rows();
+      };
+      // the stripes do not end level: room for the fullest one's lead over the average
+      auto striped_cap = [](uint64_t cap) { return cap + cap / 8 + ((uint64_t)kStripes << kStripeGroupBits) * 2; };
       for (int k = 0; k < nsteps; ++k) {
         const PlanRel& r = plan.rels[k];
         const bool last = k == nsteps - 1;
@@ -1019,7 +1107,14 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
             else launches.push_back([=](const Prologue&, const Epilogue&, unsigned) { DX_HIP(hipMemcpyAsync(cnt, &t->rows, 8, hipMemcpyHostToDevice, s)); });
             step_cap[k] = t->rows;
           } else {
-            const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : r.rows_upper, 1);
+            uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : r.rows_upper, 1);
+            if (stripe_output(k) && striped_cap(cap) < (1ull << 32)) {
+              if (!caps[k]) cap = striped_cap(cap);
+              striped |= 1u << k;
+              I.stripes = kStripes;
+              cnt = stripes_p + k;
+              I.count = cnt;
+            }
             for (int c = 0; c < r.ncols; ++c) { step_cols[k].emplace_back(pool, cap); I.col[c] = step_cols[k].back().p; }
             I.cap = (uint32_t)cap;
             step_cap[k] = cap;
@@ -1097,7 +1192,15 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           // optimistic capacity: what flows in, or twice the estimate if that is more; a miss costs one re-run
           const uint64_t guess = std::max<uint64_t>(std::max<uint64_t>(I.cap, r.rows_upper),
                                                     (uint64_t)std::min(2.0 * plan.est_rows[k], 4.0e8));
-          const uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : guess, 1);
+          uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : guess, 1);
+          if (stripe_output(k) && striped_cap(cap) < (1ull << 32)) {
+            if (!caps[k]) cap = striped_cap(cap);
+            striped |= 1u << k;
+            out.stripes = kStripes;
+            cnt = stripes_p + k;
+            out.count = cnt;
+            pa.out_count = cnt;
+          }
           if (cap >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
           for (int c = 0; c < out.ncols; ++c) { step_cols[k].emplace_back(pool, cap); out.col[c] = step_cols[k].back().p; }
           out.cap = (uint32_t)cap;
@@ -1144,6 +1247,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         ep.counters = counters_p; ep.n = MAXSTEPS + 2;
         ep.ticket = counters_p + MAXSTEPS + 2;
         ep.host_counters = hd->counters; ep.host_seq = &hd->seq; ep.seq = seq;
+        ep.stripe_counters = stripes_p; ep.host_extent = hd->extent; ep.striped = striped;
         const Prologue no_pro{};
         const Epilogue no_ep{};
         const unsigned min_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(fill_blocks, 1024));
@@ -1182,9 +1286,12 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
       const bool final_counts_only = mode == DX_QUERY_COUNT;
       for (int k = 0; k < nsteps; ++k) {
         if (k == nsteps - 1 && final_counts_only) break;
-        if (hb->counters[k] > step_cap[k]) {
-          if (hb->counters[k] >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
-          caps[k] = hb->counters[k];
+        // a striped relation needs room up to its fullest stripe's last group (the same again when the statement is re-run:
+        // which block claims from which stripe does not change)
+        const uint64_t need = (striped >> k & 1) ? hb->extent[k] : hb->counters[k];
+        if (need > step_cap[k]) {
+          if (need >= (1ull << 32)) throw DxError(DX_E_RANGE, "intermediate result with 2^32 rows or more");
+          caps[k] = need;
           overflow = true;
           break;  // later counters were computed from a truncated input
         }

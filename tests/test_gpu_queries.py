@@ -57,6 +57,65 @@ def test_lubm_query_counts_and_bindings(loaded, lubm1, name):
     assert rows == ref["rows"], name  # sorted decoded bindings, bit-exact
 
 
+@pytest.mark.parametrize("stripe_rows", ["1", "0"])
+def test_striped_intermediates_change_nothing(loaded, lubm1, monkeypatch, stripe_rows):
+    """A large intermediate that a hash join reads is written in eight stripes with a row counter each (the blocks'
+    claims then do not queue on one word); DX_JOIN_STRIPE_ROWS is the size from which (default 65536, more than LUBM-1
+    produces; 1: whenever possible, 0: never). Counts and bindings are the oracle's either way."""
+    from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
+    from oracle.query_oracle import run_query
+    e, translated = loaded
+    monkeypatch.setenv("DX_JOIN_STRIPE_ROWS", stripe_rows)
+    monkeypatch.setenv("DX_NO_PLAN_CACHE", "1")
+    for name in ("Q2.txt", "Q9.txt", "Q8.txt", "Q4.txt", "Q7.txt", "Q12.txt"):
+        ref = run_query(lubm1["oracle"]["vp"], translated[name])
+        res, _ = _run_file(e, translated[name], DX_QUERY_COUNT)
+        assert res.count == ref["count"], name
+        res_b, _ = _run_file(e, translated[name], DX_QUERY_BINDINGS)
+        rows, cols = res_b.rows()
+        assert (res_b.count, cols) == (ref["count"], ref["columns"]), name
+        assert rows == ref["rows"], name
+        # the same statement again: the counters the stripes use are back at zero
+        again, _ = _run_file(e, translated[name], DX_QUERY_COUNT)
+        assert again.count == ref["count"], name
+
+
+def test_striped_intermediates_at_a_size_that_stripes_by_itself(monkeypatch):
+    """LUBM-16: the first intermediates of Q2 and Q9 hold more than 65536 rows, so they are striped without any
+    switch; the bindings are those of the unstriped run, and a statement whose stripes outgrow the buffer's first
+    size (the estimate of a join's output is low) runs again and arrives at the same rows."""
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from opus_amd import lubm
+    from opus_amd.engine import DX_QUERY_BINDINGS, Engine
+    arr, _ = lubm.generate(0, 16, seed=3, ontology=0, degree_pool=2)
+    ci_text = lubm.class_index_text(4, 0)
+    e = Engine(0)
+    try:
+        e.partition_text(arr, ci_text, 4)
+        queries = bench.translated_queries(e, ci_text, 0)
+        striped_somewhere = False
+        for name in ("Q2.txt", "Q9.txt", "Q8.txt"):
+            sql, tabs = bench.parse_translated(queries[name])
+            got = {}
+            for rows_from in ("0", "65536"):
+                monkeypatch.setenv("DX_JOIN_STRIPE_ROWS", rows_from)
+                e.unload_all()
+                for p in tabs:
+                    e.load_table(p)
+                r = e.query(sql, DX_QUERY_BINDINGS)
+                ids = r.ids(sort=True)
+                got[rows_from] = (r.count, r.columns, ids.tobytes())
+                steps = [ln for ln in r.plan.split("\n") if "->" in ln]
+                striped_somewhere |= rows_from != "0" and any(int(ln.rsplit("->", 1)[1].split()[0]) >= 65536 for ln in steps[:-1])
+            assert got["0"] == got["65536"], name
+            assert got["0"][0] > 0 and len(got["0"][2]) == 8 * got["0"][0] * len(got["0"][1]), name
+        assert striped_somewhere
+    finally:
+        e.close()
+
+
 def test_remembered_parse_and_join_order_change_nothing(loaded, lubm1, monkeypatch):
     """A statement that comes again skips the parser and the join-order search (its text and the statistics the
     search looked at are the key): same plan, same count as with DX_NO_PLAN_CACHE=1, which always parses and searches."""
