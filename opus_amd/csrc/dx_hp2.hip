@@ -596,6 +596,128 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
   stmt_epilogue(ep);
 }
 
+// ---- the same join with the roles exchanged: the table is built over the arm's rows (those that pass its filters)
+// and the intermediate is streamed past it. Chosen when the arm is expected to be much smaller than the intermediate:
+// entering a row costs about as much as probing with one, and a table over few rows stays in cache. The chain of
+// arm row i continues at next[i]; a link is checked against the arm's own columns.
+__device__ __forceinline__ void arm_tuple(const ArmDev& a, int64_t want_s, int64_t want_o, uint32_t i, int64_t v[3]) {  // of a row that passes the filters
+  if (a.direct) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < a.nsrc) v[k] = a.d[k][i];
+    return;
+  }
+  bool need_s = false, need_o = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < a.nsrc) { need_s |= a.src[k] == 0; need_o |= a.src[k] == 1; }
+  const int64_t s = a.fs >= 0 ? want_s : need_s ? a.s[i] : 0, o = a.fo >= 0 ? want_o : need_o ? a.o[i] : 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < a.nsrc) v[k] = a.src[k] == 0 ? s : a.src[k] == 1 ? o : a.src_val[k];
+}
+template <int kRowsPerThread>
+__global__ void __launch_bounds__(256) k_build_arm(ProbeArgs p, uint32_t* __restrict__ heads, uint32_t* __restrict__ next) {
+  constexpr int kTileRows = 256 * kRowsPerThread;
+  const int64_t want_s = (!p.arm.direct && p.arm.fs >= 0) ? p.consts[p.arm.fs] : 0, want_o = (!p.arm.direct && p.arm.fo >= 0) ? p.consts[p.arm.fo] : 0;
+  const uint32_t ntiles = (p.arm.rows + kTileRows - 1) / kTileRows;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t v[kRowsPerThread][3];
+    uint32_t pass = 0;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
+      if (i < p.arm.rows && arm_row(p.arm, p.consts, want_s, want_o, i, v[j])) pass |= 1u << j;
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      if (!(pass & (1u << j))) continue;
+      const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
+      const int64_t k0 = pick3(v[j], p.key_src[0]);
+      const uint32_t h = p.nkey == 2 ? head_of2(k0, pick3(v[j], p.key_src[1]), p.near, p.near_b) : head_of(k0, p.near);
+      next[i] = atomicExch(&heads[h & p.hmask], i);
+    }
+  }
+}
+// p.heads / p.next: the table over the arm (k_build_arm). Output rows as k_probe's: the intermediate's columns, then the new ones.
+template <int kRowsPerThread>
+__global__ void __launch_bounds__(256) k_probe_rev(ProbeArgs p, Epilogue ep) {
+  constexpr int kTileRows = 256 * kRowsPerThread;
+  const uint32_t nI = rel_rows(p.I);
+  const int64_t want_s = (!p.arm.direct && p.arm.fs >= 0) ? p.consts[p.arm.fs] : 0, want_o = (!p.arm.direct && p.arm.fo >= 0) ? p.consts[p.arm.fo] : 0;
+  auto matches = [&](const int64_t (&v)[3], int64_t k0, int64_t k1) {
+    return pick3(v, p.key_src[0]) == k0 && (p.nkey < 2 || pick3(v, p.key_src[1]) == k1);
+  };
+  const uint32_t ntiles = (nI + kTileRows - 1) / kTileRows;
+  unsigned long long local = 0;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform
+    int64_t k0[kRowsPerThread], k1[kRowsPerThread];
+    uint32_t head[kRowsPerThread], hit[kRowsPerThread], nhit[kRowsPerThread];
+    uint32_t n = 0;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      const uint32_t r = tile * kTileRows + j * 256 + threadIdx.x;
+      head[j] = kNil;
+      k0[j] = k1[j] = 0;
+      if (r < nI && row_is_there(p.I, r)) {
+        k0[j] = p.I.col[p.key_col[0]][r];
+        if (p.nkey == 2) k1[j] = p.I.col[p.key_col[1]][r];
+        const uint32_t h = p.nkey == 2 ? head_of2(k0[j], k1[j], p.near, p.near_b) : head_of(k0[j], p.near);
+        head[j] = p.heads[h & p.hmask];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      hit[j] = kNil;
+      nhit[j] = 0;
+      for (uint32_t i = head[j]; i != kNil; i = p.next[i]) {
+        int64_t v[3];
+        arm_tuple(p.arm, want_s, want_o, i, v);
+        if (matches(v, k0[j], k1[j])) {
+          if (!nhit[j]) hit[j] = i;
+          ++nhit[j];
+        }
+      }
+      n += nhit[j];
+    }
+    if (p.count_only) { local += n; continue; }
+    uint32_t before;
+    unsigned long long idx = block_claim(n, claim_counter(p.out, p.out_count), before) + before;
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+      if (!nhit[j]) continue;
+      const uint32_t r = tile * kTileRows + j * 256 + threadIdx.x;
+      const bool single = nhit[j] == 1;
+      for (uint32_t i = single ? hit[j] : head[j]; i != kNil; i = single ? kNil : p.next[i]) {
+        int64_t v[3];
+        arm_tuple(p.arm, want_s, want_o, i, v);
+        if (!single && !matches(v, k0[j], k1[j])) continue;
+        const uint64_t pos = out_row(p.out, idx);
+        if (pos < p.out.cap) {
+          for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
+          for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = pick3(v, p.new_src[c]);
+        }
+        ++idx;
+      }
+    }
+  }
+  if (p.count_only) {  // one atomic per block
+    __shared__ uint64_t lds64[8];
+    uint64_t block_total;
+    (void)block_excl_scan_256<uint64_t>(local, lds64, block_total);
+    stmt_epilogue(ep, block_total, p.out_count);
+    return;
+  }
+  stmt_epilogue(ep);
+}
+
+// DX_JOIN_REVERSE: 0 = the table is always built over the intermediate, 1 = over the arm whenever that is possible;
+// otherwise over the arm when it is expected to hold at most half as many rows as the intermediate
+static int join_reverse_mode() {
+  const char* e = getenv("DX_JOIN_REVERSE");  // (read per statement: the tests switch it)
+  return !e ? -1 : atoi(e);
+}
+
 // DX_JOIN_NEAR_BITS: how many low bits of a join key choose the head inside a block of neighbouring heads (0: none)
 static int join_near_bits() {
   static const int bits = [] { const char* e = getenv("DX_JOIN_NEAR_BITS"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : v > 16 ? 16 : v; }();
@@ -1055,6 +1177,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
       unsigned long long preset_value = 0;
       // Which steps join how: known before anything is laid out, because a step's output is striped (see RelDev) only
       // when the step that reads it is a hash join with its table in HBM.
+      const bool no_lds_tables = getenv("DX_JOIN_NO_LDS") != nullptr;  // every join's table in HBM (the tests ask for it)
       std::vector<int> step_nkey(nsteps, 0);
       std::vector<char> step_small(nsteps, 0);
       {
@@ -1065,7 +1188,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
             if (std::find(cls.begin(), cls.end(), r.cls[c]) != cls.end()) ++step_nkey[k];
             else cls.push_back(r.cls[c]);
           step_small[k] = fused && step_nkey[k] > 0 && !(regular_steps & (1ull << k)) && k - 1 < (int)plan.est_rows.size() &&
-                          plan.est_rows[k - 1] <= kLdsRows / 4;
+                          plan.est_rows[k - 1] <= kLdsRows / 4 && !no_lds_tables;
         }
       }
       uint32_t striped = 0;
@@ -1153,11 +1276,28 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         if ((int)I_cls.size() + pa.nnew > MAXC) throw DxError(DX_E_UNSUPPORTED, "SQL: intermediate wider than 10 columns");
         // An intermediate the planner expects to be small gets its table in LDS, block by block, inside the probe
         // (k_probe<.., true>); if it is not small after all, the step says so and the statement runs again without.
-        const bool small = fused && pa.nkey > 0 && !(regular_steps & (1ull << k)) &&
-                           k - 1 < (int)plan.est_rows.size() && plan.est_rows[k - 1] <= kLdsRows / 4;
+        const bool small = step_small[k] != 0;
         pa.small_failed = counters_p + MAXSTEPS + 1;
         pa.step = k;
-        if (pa.nkey > 0 && !small) {
+        size_t arms_here = 0;
+        const PlanRel::Arm* only_arm = nullptr;
+        for (const auto& a : r.arms)
+          if (a.t->rows) { ++arms_here; only_arm = &a; }
+        bool reverse = false;
+        if (pa.nkey > 0 && !small && arms_here == 1 && join_reverse_mode() != 0) {
+          const double i_est = k - 1 < (int)plan.est_rows.size() ? plan.est_rows[k - 1] : (double)I.cap;
+          reverse = join_reverse_mode() > 0 || 2.0 * std::min<double>(r.est, (double)only_arm->t->rows) <= i_est;
+        }
+        if (reverse) {
+          const uint64_t arm_rows = only_arm->t->rows;
+          const uint64_t expect = std::min<uint64_t>(arm_rows, std::max<uint64_t>((uint64_t)std::min(4.0 * r.est, 4.0e9), arm_rows / 16));
+          uint32_t hsize = 1024;
+          while (hsize < 2ull * expect && hsize < (1u << 31)) hsize <<= 1;
+          my_heads_off = heads_words;
+          heads_words += hsize;
+          tmp32.emplace_back(pool, std::max<uint64_t>(arm_rows, 1));
+          pa.next = tmp32.back().p; pa.hmask = hsize - 1; pa.near = join_near_bits(); pa.near_b = join_near_b_bits();
+        } else if (pa.nkey > 0 && !small) {
           // Chained table: any number of heads is correct, fewer only means longer chains. Two heads per row
           // that is expected (four times the planner's estimate, to be safe), never fewer than a sixteenth of the
           // rows that could arrive: the heads of all steps are filled before the first scan and read at random by the
@@ -1207,6 +1347,27 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           step_cap[k] = cap;
         }
         pa.out = out;
+        if (reverse) {
+          pa.arm = arm_dev(r, *only_arm);
+          const uint64_t arm_rows = only_arm->t->rows;
+          const uint64_t off_words = my_heads_off;
+          DevBuf<uint32_t>* arena = &heads_arena;
+          uint32_t* next = tmp32.back().p;
+          const uint32_t icap = I.cap;
+          ProbeArgs pv = pa;
+          launches.push_back([=](const Prologue&, const Epilogue&, unsigned) {
+            if (arm_rows <= kSmallTable) hipLaunchKernelGGL(k_build_arm<1>, dim3(tile_grid(arm_rows, 1)), dim3(256), 0, s, pv, arena->p + off_words, next);
+            else hipLaunchKernelGGL(k_build_arm<4>, dim3(tile_grid(arm_rows, 4)), dim3(256), 0, s, pv, arena->p + off_words, next);
+          });
+          launches.push_back([=](const Prologue&, const Epilogue& ep, unsigned) mutable {
+            pv.heads = arena->p + off_words;
+            if (icap <= kSmallTable) hipLaunchKernelGGL(k_probe_rev<1>, dim3(tile_grid(icap, 1)), dim3(256), 0, s, pv, ep);
+            else hipLaunchKernelGGL(k_probe_rev<4>, dim3(tile_grid(icap, 4)), dim3(256), 0, s, pv, ep);
+          });
+          I = out;
+          for (int c : new_cls) I_cls.push_back(c);
+          continue;
+        }
         for (const auto& a : r.arms) {
           if (!a.t->rows) continue;
           pa.arm = arm_dev(r, a);

@@ -57,17 +57,28 @@ def test_lubm_query_counts_and_bindings(loaded, lubm1, name):
     assert rows == ref["rows"], name  # sorted decoded bindings, bit-exact
 
 
-@pytest.mark.parametrize("stripe_rows", ["1", "0"])
-def test_striped_intermediates_change_nothing(loaded, lubm1, monkeypatch, stripe_rows):
-    """A large intermediate that a hash join reads is written in eight stripes with a row counter each (the blocks'
-    claims then do not queue on one word); DX_JOIN_STRIPE_ROWS is the size from which (default 65536, more than LUBM-1
-    produces; 1: whenever possible, 0: never). Counts and bindings are the oracle's either way."""
+@pytest.mark.parametrize("switches", [{"DX_JOIN_STRIPE_ROWS": "1"}, {"DX_JOIN_STRIPE_ROWS": "0"},
+                                      {"DX_JOIN_STRIPE_ROWS": "1", "DX_JOIN_NO_LDS": "1"},
+                                      {"DX_JOIN_REVERSE": "1", "DX_JOIN_NO_LDS": "1"},
+                                      {"DX_JOIN_REVERSE": "1", "DX_JOIN_NO_LDS": "1", "DX_JOIN_STRIPE_ROWS": "1"},
+                                      {"DX_JOIN_REVERSE": "0", "DX_JOIN_NO_LDS": "1"}],
+                         ids=lambda d: ",".join("%s=%s" % (k[3:], v) for k, v in sorted(d.items())))
+def test_join_variants_change_nothing(loaded, lubm1, monkeypatch, switches):
+    """The ways a join step can be carried out, each forced on every step it can apply to:
+    * a large intermediate that a hash join reads is written in eight stripes with a row counter each (the blocks'
+      claims then do not queue on one word); DX_JOIN_STRIPE_ROWS is the size from which (default 65536, more than
+      LUBM-1 produces; 1: whenever possible, 0: never);
+    * the hash table is built over the arriving table's rows and the intermediate streamed past it when the table
+      is expected to be the smaller side (DX_JOIN_REVERSE 1: whenever possible, 0: never);
+    * DX_JOIN_NO_LDS keeps every join's table in HBM (small intermediates otherwise get theirs in LDS).
+    Counts and bindings are the oracle's every time."""
     from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
     from oracle.query_oracle import run_query
     e, translated = loaded
-    monkeypatch.setenv("DX_JOIN_STRIPE_ROWS", stripe_rows)
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
     monkeypatch.setenv("DX_NO_PLAN_CACHE", "1")
-    for name in ("Q2.txt", "Q9.txt", "Q8.txt", "Q4.txt", "Q7.txt", "Q12.txt"):
+    for name in ("Q2.txt", "Q9.txt", "Q8.txt", "Q4.txt", "Q7.txt", "Q12.txt", "Q1.txt"):
         ref = run_query(lubm1["oracle"]["vp"], translated[name])
         res, _ = _run_file(e, translated[name], DX_QUERY_COUNT)
         assert res.count == ref["count"], name
@@ -82,7 +93,8 @@ def test_striped_intermediates_change_nothing(loaded, lubm1, monkeypatch, stripe
 
 def test_striped_intermediates_at_a_size_that_stripes_by_itself(monkeypatch):
     """LUBM-16: the first intermediates of Q2 and Q9 hold more than 65536 rows, so they are striped without any
-    switch; the bindings are those of the unstriped run, and a statement whose stripes outgrow the buffer's first
+    switch; the bindings are those of the unstriped run (also with every table built over the arriving arm, which
+    then streams a striped intermediate), and a statement whose stripes outgrow the buffer's first
     size (the estimate of a join's output is low) runs again and arrives at the same rows."""
     import sys
     sys.path.insert(0, os.path.dirname(HERE))
@@ -99,8 +111,9 @@ def test_striped_intermediates_at_a_size_that_stripes_by_itself(monkeypatch):
         for name in ("Q2.txt", "Q9.txt", "Q8.txt"):
             sql, tabs = bench.parse_translated(queries[name])
             got = {}
-            for rows_from in ("0", "65536"):
-                monkeypatch.setenv("DX_JOIN_STRIPE_ROWS", rows_from)
+            for rows_from in ("0", "65536", "65536r"):
+                monkeypatch.setenv("DX_JOIN_STRIPE_ROWS", rows_from.rstrip("r"))
+                monkeypatch.setenv("DX_JOIN_REVERSE", "1" if rows_from.endswith("r") else "0")
                 e.unload_all()
                 for p in tabs:
                     e.load_table(p)
@@ -109,7 +122,7 @@ def test_striped_intermediates_at_a_size_that_stripes_by_itself(monkeypatch):
                 got[rows_from] = (r.count, r.columns, ids.tobytes())
                 steps = [ln for ln in r.plan.split("\n") if "->" in ln]
                 striped_somewhere |= rows_from != "0" and any(int(ln.rsplit("->", 1)[1].split()[0]) >= 65536 for ln in steps[:-1])
-            assert got["0"] == got["65536"], name
+            assert got["0"] == got["65536"] == got["65536r"], name
             assert got["0"][0] > 0 and len(got["0"][2]) == 8 * got["0"][0] * len(got["0"][1]), name
         assert striped_somewhere
     finally:
