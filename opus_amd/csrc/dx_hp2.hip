@@ -730,8 +730,10 @@ static uint64_t join_stripe_rows() {
   return e ? (uint64_t)strtoull(e, nullptr, 10) : 65536ull;
 }
 
+// DX_JOIN_NEAR_B: how many low bits of a two-column key's second column are left out of the mixing, so that rows whose
+// second keys lie close together (ids handed out together) start their chains in the same neighbourhood of heads
 static int join_near_b_bits() {
-  static const int bits = [] { const char* e = getenv("DX_JOIN_NEAR_B"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > 16 ? 16 : v; }();
+  static const int bits = [] { const char* e = getenv("DX_JOIN_NEAR_B"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : v > 16 ? 16 : v; }();
   return bits;
 }
 
