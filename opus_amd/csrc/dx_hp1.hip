@@ -835,7 +835,7 @@ k_tokenise(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restr
 
 // ---- 3. dictionary ---------------------------------------------------------------------------------
 // The kernels over the tiles' entries give one wave to a tile: its entries are [3 * first_rec, + leaders).
-constexpr int EN_TILES_PER_BLOCK = 4;
+constexpr int EN_TILES_PER_BLOCK = 1;
 
 // Every entry claims / finds the slot of its hash and lowers the slot's representative to the smallest
 // (offset, length) word, i.e. the first occurrence in the text: ids do not depend on timing.
