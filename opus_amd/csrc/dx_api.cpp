@@ -259,7 +259,6 @@ void dx_free(dx_ctx* ctx) {
   ctx->dict = Dictionary();
   ctx->qws.reset();
   ctx->pool.trim();
-  if (ctx->q_ev0) { (void)hipEventDestroy(ctx->q_ev0); (void)hipEventDestroy(ctx->q_ev1); }
   if (ctx->q_host) (void)hipHostFree(ctx->q_host);
   if (ctx->q_counters) (void)hipFree(ctx->q_counters);
   for (int b = 0; b < kFileStages; ++b) {

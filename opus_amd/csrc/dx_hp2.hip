@@ -160,7 +160,9 @@ k_resolve_consts(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, u
 __global__ void __launch_bounds__(256)
 k_query_init(ConstArgs ca, uint64_t seed, const DictSlot* __restrict__ ht, uint64_t mask, const uint8_t* __restrict__ pool,
              const uint64_t* __restrict__ pool_off, int64_t* __restrict__ consts, unsigned long long* __restrict__ counters, int n_counters,
-             uint32_t* __restrict__ heads, uint64_t n_heads, unsigned long long* preset_counter = nullptr, unsigned long long preset_value = 0) {
+             uint32_t* __restrict__ heads, uint64_t n_heads, unsigned long long* preset_counter = nullptr, unsigned long long preset_value = 0,
+             unsigned long long* t_begin = nullptr) {
+  if (t_begin && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(t_begin, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if ((int)blockIdx.x < ca.n && threadIdx.x < 64) resolve_const(ca, blockIdx.x, threadIdx.x, seed, ht, mask, pool, pool_off, consts);
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
   if (t < (uint64_t)n_counters) counters[t] = 0;
@@ -192,6 +194,7 @@ struct Prologue {
   int64_t* consts;
   uint32_t* heads;
   uint64_t n_heads;                       // multiple of four
+  unsigned long long* t_begin;            // the device's wall clock when the statement's first kernel began (its first block)
 };
 struct Epilogue {
   int enabled;
@@ -201,6 +204,8 @@ struct Epilogue {
   unsigned long long* host_counters;
   unsigned long long* host_seq;
   unsigned long long seq;
+  unsigned long long* t_begin;          // written by the statement's first kernel
+  unsigned long long* host_clock;       // [0] the device's wall clock at the first kernel's begin, [1] at the last kernel's end
   unsigned long long* stripe_counters;  // step k's stripe x: [x * kStripeStride + k]
   unsigned long long* host_extent;      // per striped step: one past the last row of its relation that is in use
   uint32_t striped;                     // bit k: step k's relation is striped (its row counter is the sum of its stripes')
@@ -218,6 +223,7 @@ __device__ __forceinline__ void stmt_prologue(const Prologue& pro, int fs, int f
   }
   __shared__ long long own[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pro.t_begin, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (wave == 0) {
     for (int c = blockIdx.x; c < pro.ca.n; c += gridDim.x) resolve_const(pro.ca, c, lane, 0, pro.ht, pro.mask, pro.pool, pro.pool_off, pro.consts);
   } else if (wave == 1) {
@@ -292,6 +298,10 @@ __device__ __forceinline__ void stmt_epilogue(const Epilogue& ep, unsigned long 
     if (add_to && add_to == &ep.counters[threadIdx.x]) v += total_s;  // a counter other kernels of the step have added to as well
     __hip_atomic_store(&ep.host_counters[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&ep.counters[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 64) {  // a wave of its own, beside the counters' stores
+    __hip_atomic_store(&ep.host_clock[0], __hip_atomic_load(ep.t_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&ep.host_clock[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence_system();
   __syncthreads();
@@ -1029,13 +1039,15 @@ void launch_probe(hipStream_t s, uint64_t rows, const ProbeArgs& p, const Epilog
 // device block of a context: row counters and tickets (see Epilogue)
 // ... and, from a multiple of 256 bytes on, the stripes' row counters of striped relations (see RelDev)
 constexpr size_t kStripeCountersAt = (MAXSTEPS + 2 + 1 + kSubTickets + kStripeStride - 1) / kStripeStride * kStripeStride;  // in words
-constexpr size_t kQueryCounterBytes = sizeof(unsigned long long) * (kStripeCountersAt + kStripes * kStripeStride);
+constexpr size_t kClockWordAt = kStripeCountersAt + kStripes * kStripeStride;  // ... and the first kernel's begin on the device's wall clock
+constexpr size_t kQueryCounterBytes = sizeof(unsigned long long) * (kClockWordAt + 1);
 static_assert(MAXSTEPS <= (int)kStripeStride && MAXSTEPS <= 32, "a word per step between two stripes, a bit per step in Epilogue::striped");
 // Pinned host block the final counters land in.
 constexpr int kShardedWords = 2 * 64 + 8;
 struct QueryHostBlock {
   unsigned long long counters[MAXSTEPS + 2];
   unsigned long long extent[MAXSTEPS + 2];    // striped relations: rows of the buffer in use (see Epilogue::host_extent)
+  unsigned long long clock[2];                // the device's wall clock: first kernel's begin, last kernel's end
   unsigned long long seq;                     // number of the statement whose counters these are (written last)
   unsigned long long sharded[kShardedWords];  // several GPUs: row counts per destination rank on their way to the host
 };
@@ -1047,8 +1059,12 @@ struct QueryHostBlock {
 // (a copy engine's transfer plus the runtime's wake-up cost more than the statement's kernels for a short one).
 __global__ void __launch_bounds__(64)
 k_publish(const unsigned long long* __restrict__ counters, int n, unsigned long long* host_counters, unsigned long long* host_seq,
-          unsigned long long seq) {
+          unsigned long long seq, const unsigned long long* __restrict__ t_begin, unsigned long long* host_clock) {
   if ((int)threadIdx.x < n) __hip_atomic_store(&host_counters[threadIdx.x], counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 63) {
+    __hip_atomic_store(&host_clock[0], *t_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host_clock[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __threadfence_system();
   if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1071,16 +1087,7 @@ static void wait_published(dx_ctx* ctx, QueryHostBlock* hb, uint64_t seq) {
   if (hb->seq != seq) throw DxError(DX_E_HIP, "the statement's counters did not arrive on the host");
 }
 
-double result_device_ms(dx_result* r) {
-  if (r->device_ms >= 0) return r->device_ms;
-  dx_ctx* ctx = r->ctx;
-  r->device_ms = 0;
-  if (ctx && ctx->q_seq == r->timing_seq && ctx->q_ev1) {  // the events have not been recorded again since
-    float ms = 0;
-    if (hipEventSynchronize(ctx->q_ev1) == hipSuccess && hipEventElapsedTime(&ms, ctx->q_ev0, ctx->q_ev1) == hipSuccess) r->device_ms = ms;
-  }
-  return r->device_ms;
-}
+double result_device_ms(dx_result* r) { return r->device_ms; }
 
 void query_context_setup(dx_ctx* ctx) {
   if (!ctx->q_host) {
@@ -1092,7 +1099,11 @@ void query_context_setup(dx_ctx* ctx) {
     DX_HIP(hipMalloc(&ctx->q_counters, kQueryCounterBytes));
     DX_HIP(hipMemset(ctx->q_counters, 0, kQueryCounterBytes));
   }
-  if (!ctx->q_ev0) { DX_HIP(hipEventCreate(&ctx->q_ev0)); DX_HIP(hipEventCreate(&ctx->q_ev1)); }
+  if (ctx->q_clock_khz <= 0) {  // ticks of the device's wall clock (wall_clock64) per millisecond
+    int khz = 0;
+    DX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    ctx->q_clock_khz = khz > 0 ? khz : 100000;
+  }
 }
 
 static bool plan_cache_enabled() {
@@ -1138,11 +1149,10 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
   }
   ca.off[ca.n] = off;
 
-  if (!ctx->q_host || !ctx->q_ev0) throw DxError(DX_E_INVAL, "context was not set up for queries");
+  if (!ctx->q_host || !ctx->q_counters) throw DxError(DX_E_INVAL, "context was not set up for queries");
   QueryHostBlock* hb = static_cast<QueryHostBlock*>(ctx->q_host);
 
   std::vector<uint64_t> caps(nsteps, 0);
-  hipEvent_t ev0 = ctx->q_ev0, ev1 = ctx->q_ev1;
   auto* res = new dx_result();
   res->ctx = ctx;
   res->names = plan.select_names;
@@ -1159,6 +1169,8 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
     }
     const bool fused = ca.n <= kProConsts && off <= (uint32_t)kProBytes && ctx->q_counters && !getenv("DX_QUERY_UNFUSED");
     for (int attempt = 0; attempt <= 2 * nsteps + 2; ++attempt) {
+      const auto t_attempt = std::chrono::steady_clock::now();
+      auto t_laid_out = t_attempt, t_queued = t_attempt;
       if (pool.is_arena()) pool.rewind();  // a re-run with larger buffers starts from the arena's base again
       DevBuf<int64_t> consts(pool, kMaxConsts);
       DevBuf<unsigned long long> own_counters;
@@ -1388,10 +1400,11 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
       heads_arena = DevBuf<uint32_t>(pool, std::max<uint64_t>(heads_words, 4));
       const uint64_t fill_blocks = (heads_words / 4 + 255) / 256;
       const uint64_t seq = ++ctx->q_seq;
-      DX_HIP(hipEventRecord(ev0, s));
+      t_laid_out = std::chrono::steady_clock::now();
+      unsigned long long* const t_begin = static_cast<unsigned long long*>(ctx->q_counters) + kClockWordAt;
       if (fused && launches.empty()) {  // nothing to scan at all (every table named is empty): every count is zero
         for (auto& c : hb->counters) c = 0;
-        DX_HIP(hipEventRecord(ev1, s));
+        hb->clock[0] = hb->clock[1] = 0;
       } else if (fused) {
         QueryHostBlock* hd = static_cast<QueryHostBlock*>(ctx->q_host_dev);
         if (ctx->q_counters_dirty) DX_HIP(hipMemsetAsync(ctx->q_counters, 0, kQueryCounterBytes, s));
@@ -1405,12 +1418,14 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         pro.ht = ctx->dict.ht.p; pro.mask = ctx->dict.ht_mask; pro.pool = ctx->dict.pool.p; pro.pool_off = ctx->dict.pool_off.p;
         pro.consts = consts.p;
         pro.heads = heads_arena.p; pro.n_heads = heads_words;
+        pro.t_begin = t_begin;
         Epilogue ep{};
         ep.enabled = 1;
         ep.counters = counters_p; ep.n = MAXSTEPS + 2;
         ep.ticket = counters_p + MAXSTEPS + 2;
         ep.host_counters = hd->counters; ep.host_seq = &hd->seq; ep.seq = seq;
         ep.stripe_counters = stripes_p; ep.host_extent = hd->extent; ep.striped = striped;
+        ep.t_begin = t_begin; ep.host_clock = hd->clock;
         const Prologue no_pro{};
         const Epilogue no_ep{};
         const unsigned min_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(fill_blocks, 1024));
@@ -1420,23 +1435,23 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         if (own_init) {
           const unsigned grid = (unsigned)std::max<uint64_t>(std::max<uint64_t>(ca.n, 1), std::min<uint64_t>(fill_blocks, 2048));
           hipLaunchKernelGGL(k_query_init, dim3(grid), dim3(256), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
-                             ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters_p, 0, heads_arena.p, heads_words, preset_counter, preset_value);
+                             ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters_p, 0, heads_arena.p, heads_words, preset_counter, preset_value, t_begin);
         }
         for (size_t i = 0; i < launches.size(); ++i)
           launches[i](i == 0 && !own_init ? pro : no_pro, i + 1 == launches.size() ? ep : no_ep, min_grid);
-        DX_HIP(hipEventRecord(ev1, s));
+        t_queued = std::chrono::steady_clock::now();
         wait_published(ctx, hb, seq);
         ctx->q_counters_dirty = false;
       } else {
         const unsigned grid = (unsigned)std::max<uint64_t>(std::max<uint64_t>(ca.n, 1), std::min<uint64_t>(fill_blocks, 2048));
         hipLaunchKernelGGL(k_query_init, dim3(grid), dim3(256), 0, s, ca, ctx->dict.seed, ctx->dict.ht.p, ctx->dict.ht_mask,
-                           ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters_p, MAXSTEPS + 2, heads_arena.p, heads_words);
+                           ctx->dict.pool.p, ctx->dict.pool_off.p, consts.p, counters_p, MAXSTEPS + 2, heads_arena.p, heads_words,
+                           (unsigned long long*)nullptr, 0ull, t_begin);
         const Prologue no_pro{};
         const Epilogue no_ep{};
         for (auto& f : launches) f(no_pro, no_ep, 1);
         QueryHostBlock* hd = static_cast<QueryHostBlock*>(ctx->q_host_dev);
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, counters_p, MAXSTEPS + 2, hd->counters, &hd->seq, (unsigned long long)seq);
-        DX_HIP(hipEventRecord(ev1, s));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, counters_p, MAXSTEPS + 2, hd->counters, &hd->seq, (unsigned long long)seq, t_begin, hd->clock);
         wait_published(ctx, hb, seq);
       }
       if (fused && hb->counters[MAXSTEPS + 1]) {  // some step's intermediate did not fit its table in LDS
@@ -1460,8 +1475,9 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         }
       }
       if (overflow) continue;
-      res->device_ms = -1;  // read from the events when asked for, as long as no later statement has recorded them again
-      res->timing_seq = ctx->q_seq;
+      // from the first kernel's begin to the last kernel's end by the device's own wall clock (no events in the queue:
+      // each is a packet of its own before and after the kernels, and a call on the host)
+      res->device_ms = hb->clock[1] > hb->clock[0] ? (double)(hb->clock[1] - hb->clock[0]) / ctx->q_clock_khz : 0.0;
       res->count = hb->counters[nsteps - 1];
       res->global_count = res->count;
       if (mode == DX_QUERY_BINDINGS) {
@@ -1478,6 +1494,13 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         DX_HIP(hipStreamSynchronize(s));
       }
       res->plan_us = plan_us;  // the text of the plan is put together when it is asked for
+      {
+        const auto t_done = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        res->host_us[0] = us(t_attempt, t_laid_out);
+        res->host_us[1] = us(t_laid_out, t_queued);
+        res->host_us[2] = us(t_queued, t_done);
+      }
       res->plan_steps.resize(nsteps);
       for (int k = 0; k < nsteps; ++k) {
         const PlanRel& r = plan.rels[k];

@@ -155,7 +155,7 @@ struct dx_ctx {
   int ds_partitions = 0;
   // query workspace
   dx::DevBuf<uint8_t> qws;
-  hipEvent_t q_ev0 = nullptr, q_ev1 = nullptr;
+  double q_clock_khz = 0;               // ticks of the device's wall clock per millisecond
   void* q_host = nullptr;               // pinned block the final counters of a statement land in
   void* q_host_dev = nullptr;           // the same block as the device addresses it
   uint64_t q_seq = 0;                   // statements run on this context so far
@@ -293,8 +293,7 @@ struct dx_result {
   dx_ctx* ctx = nullptr;
   uint64_t count = 0;         // rows held by this context
   uint64_t global_count = 0;  // rows over all ranks (== count on one GPU)
-  double device_ms = 0;       // -1: not read yet (see result_device_ms)
-  uint64_t timing_seq = 0;    // the statement whose events still hold this result's device time
+  double device_ms = 0;       // first kernel's begin to last kernel's end, by the device's wall clock
   bool has_bindings = false;
   std::vector<std::string> names;
   std::vector<dx::DevBuf<int64_t>> cols;   // one per selected column (bindings mode)
@@ -306,9 +305,11 @@ struct dx_result {
   struct PlanStep { std::vector<PlanArm> arms; uint64_t rows_out; };
   std::vector<PlanStep> plan_steps;
   double plan_us = -1;
+  double host_us[3] = {0, 0, 0};  // the last attempt's host time: buffers and arguments laid out, kernels queued, waited for the counters
   const std::string& plan_text() {
     if (plan_us >= 0) {
-      std::string t = "parse+plan " + std::to_string((long)plan_us) + " us\n";
+      std::string t = "parse+plan " + std::to_string((long)plan_us) + " us, lay out " + std::to_string((long)host_us[0]) + " us, queue " +
+                      std::to_string((long)host_us[1]) + " us, wait " + std::to_string((long)host_us[2]) + " us\n";
       for (size_t k = 0; k < plan_steps.size(); ++k) {
         t += k ? "join " : "scan ";
         for (size_t a = 0; a < plan_steps[k].arms.size(); ++a) {
@@ -388,7 +389,7 @@ const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t);
 void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip
 dx_result* run_query(dx_ctx* ctx, const std::string& sql, int mode);
-double result_device_ms(dx_result* r);  // device time of the statement, read from its events when first asked for
+double result_device_ms(dx_result* r);
 void query_context_setup(dx_ctx* ctx);                      // pinned block + events of the query path, once per context
 void* noalloc_scratch_of_current_device(size_t* bytes);     // the device array behind dx_query_count_noalloc
 uint64_t run_query_count_noalloc(dx_ctx* ctx, const std::string& sql);
