@@ -209,6 +209,10 @@ int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out);
  * through dx_query once. One GPU only (DX_E_UNSUPPORTED with a communicator set). All contexts of a GPU share
  * the array: calls that overlap in time on one GPU race, so serialise them. */
 int dx_query_count_noalloc(dx_ctx* ctx, const char* sql, uint64_t* count);
+/* The context's device allocator: buffers it has handed out since dx_init (from its cache or from hipMalloc) and the bytes
+ * of those still in use. No counterpart in the reference; for callers of dx_query_count_noalloc who want to check, as this
+ * repository's tests do, that a call left both numbers as they were. Either pointer may be NULL. */
+int dx_allocator_stats(dx_ctx* ctx, uint64_t* requests, uint64_t* live_bytes);
 uint64_t dx_result_count(dx_result* r);
 int dx_result_columns(dx_result* r);
 const char* dx_result_column_name(dx_result* r, int i);

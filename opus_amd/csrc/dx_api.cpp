@@ -869,6 +869,13 @@ int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, con
   });
 }
 
+int dx_allocator_stats(dx_ctx* ctx, uint64_t* requests, uint64_t* live_bytes) {
+  return guard(ctx, [&] {
+    if (requests) *requests = ctx->pool.requests();
+    if (live_bytes) *live_bytes = ctx->pool.live_bytes();
+  });
+}
+
 int dx_layout_times(dx_ctx* ctx, double* out, int n) {
   return guard(ctx, [&] {
     if (!out || n < 0) throw DxError(DX_E_INVAL, "null output");

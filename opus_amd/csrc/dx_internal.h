@@ -49,11 +49,13 @@ class DevPool {
   void release(void* p);   // back to the cache
   void trim();             // hipFree everything cached (live blocks stay live)
   size_t live_bytes() const { return live_bytes_; }
+  uint64_t requests() const { return requests_; }  // buffers handed out by alloc() so far, from the cache or from hipMalloc (not: pieces of an arena)
 
  private:
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> live_;
   size_t live_bytes_ = 0;
+  uint64_t requests_ = 0;
   uint8_t* arena_base_ = nullptr;
   size_t arena_bytes_ = 0, arena_used_ = 0;
 };

@@ -21,6 +21,7 @@ void* DevPool::alloc(size_t bytes) {
     arena_used_ += sz;
     return p;
   }
+  ++requests_;
   const size_t sz = round_alloc(bytes ? bytes : 1);
   auto it = free_.find(sz);
   void* p = nullptr;

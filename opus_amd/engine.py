@@ -33,7 +33,7 @@ EXPORTS = [
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
     "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
-    "dx_query_count_noalloc", "dx_rccl_unique_id", "dx_comm_rccl_init", "dx_comm_rccl_init_file", "dx_comm_rccl_init_job", "dx_comm_selftest",
+    "dx_query_count_noalloc", "dx_allocator_stats", "dx_rccl_unique_id", "dx_comm_rccl_init", "dx_comm_rccl_init_file", "dx_comm_rccl_init_job", "dx_comm_selftest",
     "dx_load_tables_sharded", "dx_import_layout",
 ]
 
@@ -119,6 +119,7 @@ def load_library():
         "dx_unload_all": (c_int, [c_void_p]),
         "dx_query": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_void_p)]),
         "dx_query_count_noalloc": (c_int, [c_void_p, c_char_p, u64p]),
+        "dx_allocator_stats": (c_int, [c_void_p, u64p, u64p]),
         "dx_result_count": (c_uint64, [c_void_p]),
         "dx_result_columns": (c_int, [c_void_p]),
         "dx_result_column_name": (c_char_p, [c_void_p, c_int]),
@@ -460,6 +461,12 @@ class Engine:
     def set_table_stats(self, key: str, stats):
         arr = (c_uint64 * 3)(int(stats[0]), int(stats[1]), int(stats[2]))
         self._check(self.lib.dx_set_table_stats(self.ctx, key.encode(), arr))
+
+    def allocator_stats(self):
+        """(buffers the context's device allocator has handed out so far, bytes of those still in use)"""
+        n, b = c_uint64(0), c_uint64(0)
+        self._check(self.lib.dx_allocator_stats(self.ctx, byref(n), byref(b)))
+        return n.value, b.value
 
     def query_count_noalloc(self, sql: str) -> int:
         """The count of query(sql), computed without any device allocation (fixed scratch array; one GPU)."""

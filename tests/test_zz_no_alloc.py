@@ -63,6 +63,32 @@ def test_counts_equal_dx_query_on_calls_in_a_row(loaded, lubm1):
     assert e.query_count_noalloc(big_sql) == e.query(big_sql).count
 
 
+@pytest.mark.parametrize("unfused", [False, True])
+def test_a_call_takes_nothing_from_any_allocator(loaded, monkeypatch, unfused):
+    """The entry point's one promise: between entering and leaving it the context's allocator hands out no buffer (not
+    even a cached one), holds the same bytes, and the device's free memory is what it was (no hipMalloc / hipFree by
+    anybody in the process). Checked for statements of every length, with the statement's preparation riding in its
+    first kernel and as kernels of its own (DX_QUERY_UNFUSED), and against dx_query, which does allocate."""
+    import torch
+    e, plans = loaded
+    if unfused:
+        monkeypatch.setenv("DX_QUERY_UNFUSED", "1")
+    for name in ("Q9.txt", "Q2.txt", "Q4.txt", "Q1.txt", "Q6.txt"):
+        sql, parts = plans[name]
+        _input_rows(e, parts)
+        want = e.query(sql).count               # also gathers whatever statistics the plan needs, as the contract asks
+        e.query_count_noalloc(sql)              # the first call may still size things on the host
+        torch.cuda.synchronize()
+        before = (e.allocator_stats(), torch.cuda.mem_get_info()[0])
+        for _ in range(3):
+            assert e.query_count_noalloc(sql) == want
+        torch.cuda.synchronize()
+        assert (e.allocator_stats(), torch.cuda.mem_get_info()[0]) == before, name
+        r = e.query(sql)                        # the allocating entry point does move the counter
+        assert e.allocator_stats()[0] > before[0][0]
+        r.close()
+
+
 def test_two_contexts_of_one_gpu_share_the_array_one_after_another(loaded):
     from opus_amd.engine import Engine
     e, plans = loaded
