@@ -675,7 +675,7 @@ int dx_measures_write(dx_ctx* ctx, const char* base, const char* dataset, const 
 }
 
 // ---- on-disk layout -----------------------------------------------------------------------------------
-// The layout with the files encoded by host threads: taken when snappy pages are asked for (DX_PARQUET_CODEC=snappy),
+// The layout with the files encoded by host threads: the earlier writer, taken only with DX_LAYOUT_WRITER=host,
 // which the GPU encoder does not make.
 static void write_layout_host(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
   {
@@ -864,7 +864,8 @@ static void write_layout_host(dx_ctx* ctx, const char* base, const char* dataset
 
 int dx_part_write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char* local_dir) {
   return guard(ctx, [&] {
-    if (parquet_writer_uses_snappy()) write_layout_host(ctx, base, dataset, local_dir);
+    const char* w = getenv("DX_LAYOUT_WRITER");  // "host": the earlier writer, pages built by host threads (kept for comparison)
+    if (w && std::string(w) == "host") write_layout_host(ctx, base, dataset, local_dir);
     else write_layout(ctx, base, dataset, local_dir);
   });
 }

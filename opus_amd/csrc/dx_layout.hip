@@ -259,7 +259,7 @@ struct EncChunk {
   uint32_t first, count;  // entries [first, first + count) of the entry list; kChunkParts: rows of the VP index
   uint32_t width, pad;
 };
-struct ChunkSize { uint32_t first, count; uint64_t bytes, start; };
+struct ChunkSize { uint32_t first, count; uint64_t bytes, start; uint64_t packed_bytes, packed_start; };  // packed: as snappy elements (terms only)
 struct EncTile { uint32_t chunk, first; };  // kTileVals values of one chunk
 constexpr uint32_t kTileVals = 2048;
 struct CopySeg { uint64_t src, dst, bytes; };  // src: offset into the uploaded bytes, or a device address
@@ -345,16 +345,23 @@ __global__ void __launch_bounds__(256)
 k_chunk_sizes(const EncChunk* __restrict__ chunks, uint32_t n_chunks, const uint64_t* __restrict__ entries, uint32_t n_sorted, int id_bits,
               const uint64_t* __restrict__ dpos, uint32_t n_entries, const uint64_t* __restrict__ dtotal,
               const uint32_t* __restrict__ rowstart, const uint64_t* __restrict__ epos, uint32_t n_vpi, const uint64_t* __restrict__ etotal,
+              const uint64_t* __restrict__ cpos /*null: pages are not packed*/, const uint64_t* __restrict__ ctotal,
+              const uint64_t* __restrict__ rpos /*null: the parts columns are not packed*/, const uint64_t* __restrict__ rtotal, uint32_t n_rows,
               ChunkSize* __restrict__ out) {
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n_chunks) return;
   const EncChunk c = chunks[k];
   ChunkSize z;
+  z.packed_bytes = z.packed_start = 0;
   if (c.kind == kChunkParts) {
     z.first = c.first; z.count = c.count;
     const uint32_t a = rowstart[c.first], b = rowstart[c.first + c.count];
     z.start = a == n_vpi ? *etotal : epos[a];
     z.bytes = (b == n_vpi ? *etotal : epos[b]) - z.start;
+    if (rpos) {
+      z.packed_start = c.first == n_rows ? *rtotal : rpos[c.first];
+      z.packed_bytes = (c.first + c.count == n_rows ? *rtotal : rpos[c.first + c.count]) - z.packed_start;
+    }
   } else {
     if (c.kind == kChunkPlain) { z.first = c.first; z.count = c.count; }
     else {
@@ -364,6 +371,10 @@ k_chunk_sizes(const EncChunk* __restrict__ chunks, uint32_t n_chunks, const uint
     const uint32_t e = z.first + z.count;
     z.start = z.first == n_entries ? *dtotal : dpos[z.first];
     z.bytes = (e == n_entries ? *dtotal : dpos[e]) - z.start;
+    if (cpos) {
+      z.packed_start = z.first == n_entries ? *ctotal : cpos[z.first];
+      z.packed_bytes = (e == n_entries ? *ctotal : cpos[e]) - z.packed_start;
+    }
   }
   out[k] = z;
 }
@@ -394,6 +405,106 @@ k_enc_terms(const uint64_t* __restrict__ entries, uint32_t n, int id_bits, const
   } else if (sub == 0) {
     for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];
   }
+}
+
+// ---- the same pages as snappy streams ----------------------------------------------------------------------------------
+// A page of terms is a list of records (4-byte length, bytes), and the terms of a page follow each other in id order, i.e.
+// in the order they first appeared in the text: a term shares most of its bytes with the one before it (the students of a
+// department, the publications of an author). So a record is written as "the first bytes of the record before it"
+// (a copy element reaching back by that record's size) and the rest as a literal; every record's elements depend on its
+// neighbour's bytes only, not on how the neighbour was packed, so all records are sized and written side by side:
+//   first record of a page, or the record before is 64 KiB or longer:   literal(length word + term)
+//   same length as the term before, m common bytes:                      copy(4 + m), literal(rest)
+//   another length, m >= 4 common bytes:                                 literal(length word), copy(m), literal(rest)
+//   otherwise:                                                           literal(length word + term)
+// Copies are the form with a 2-byte distance, at most 64 bytes each. This is not a general compressor: it looks at
+// one candidate per record. On LUBM's pages it leaves about a third of the bytes.
+struct PackPlan { uint32_t head_lit, copy, tail_lit; };  // literal bytes from the record's start, copied bytes, literal bytes to its end
+__device__ __forceinline__ uint32_t lit_bytes(uint32_t n) { return n == 0 ? 0 : n + (n <= 60 ? 1 : n <= 256 ? 2 : n <= 65536 ? 3 : n <= (1u << 24) ? 4 : 5); }
+__device__ __forceinline__ uint32_t copy_bytes(uint32_t n) { return 3 * ((n + 63) / 64); }
+__device__ __forceinline__ uint32_t pack_bytes(const PackPlan& p) { return lit_bytes(p.head_lit) + copy_bytes(p.copy) + lit_bytes(p.tail_lit); }
+__device__ __forceinline__ uint32_t common_prefix(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n) {
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, a + i, 8);
+    __builtin_memcpy(&y, b + i, 8);
+    if (x != y) return i + ((uint32_t)__builtin_ctzll(x ^ y) >> 3);
+  }
+  for (; i < n && a[i] == b[i]; ++i) {}
+  return i;
+}
+// entry j of the list and the one before it (if it belongs to the same page)
+__device__ __forceinline__ PackPlan pack_plan(const uint64_t* __restrict__ entries, uint32_t j, int id_bits, const uint8_t* __restrict__ pool,
+                                              const uint64_t* __restrict__ pool_off, uint32_t& len, uint64_t& at, uint32_t& prev_len) {
+  const uint64_t key = entries[j], id = key & ((1ull << id_bits) - 1);
+  at = pool_off[id];
+  len = (uint32_t)(pool_off[id + 1] - at);
+  prev_len = 0;
+  PackPlan p{4 + len, 0, 0};
+  if (j == 0) return p;
+  const uint64_t before = entries[j - 1];
+  if ((before >> id_bits) != (key >> id_bits)) return p;
+  const uint64_t pid = before & ((1ull << id_bits) - 1), pat = pool_off[pid];
+  prev_len = (uint32_t)(pool_off[pid + 1] - pat);
+  if (4ull + prev_len > 65535) return p;
+  const uint32_t m = common_prefix(pool + at, pool + pat, len < prev_len ? len : prev_len);
+  if (len == prev_len) return PackPlan{0, 4 + m, len - m};
+  if (m >= 4) return PackPlan{4, m, len - m};
+  return p;
+}
+__global__ void __launch_bounds__(256)
+k_entry_packed_lens(const uint64_t* __restrict__ entries, uint32_t n, int id_bits, const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
+                    uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t len, prev_len;
+  uint64_t at;
+  out[j] = pack_bytes(pack_plan(entries, j, id_bits, pool, pool_off, len, at, prev_len));
+}
+__device__ __forceinline__ uint8_t* put_literal(uint8_t* d, const uint8_t* __restrict__ a, uint32_t na, const uint8_t* __restrict__ b, uint32_t nb) {
+  const uint32_t n = na + nb;  // the literal's bytes are a[0, na) then b[0, nb)
+  if (!n) return d;
+  const uint32_t v = n - 1;
+  if (v < 60) { *d++ = (uint8_t)(v << 2); }
+  else {
+    const int bytes = v < (1u << 8) ? 1 : v < (1u << 16) ? 2 : v < (1u << 24) ? 3 : 4;
+    *d++ = (uint8_t)((59 + bytes) << 2);
+    for (int i = 0; i < bytes; ++i) *d++ = (uint8_t)(v >> (8 * i));
+  }
+  for (uint32_t i = 0; i < na; ++i) *d++ = a[i];
+  uint32_t i = 0;
+  for (; i + 8 <= nb; i += 8) {
+    uint64_t x;
+    __builtin_memcpy(&x, b + i, 8);
+    __builtin_memcpy(d + i, &x, 8);
+  }
+  for (; i < nb; ++i) d[i] = b[i];
+  return d + nb;
+}
+__global__ void __launch_bounds__(256)
+k_enc_terms_packed(const uint64_t* __restrict__ entries, uint32_t n, int id_bits, const EncChunk* __restrict__ chunks, const uint64_t* __restrict__ cpos,
+                   const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, uint8_t* __restrict__ image) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t len, prev_len;
+  uint64_t at;
+  const PackPlan p = pack_plan(entries, j, id_bits, pool, pool_off, len, at, prev_len);
+  uint8_t* d = image + chunks[entries[j] >> id_bits].adj + cpos[j];
+  const uint8_t* term = pool + at;
+  uint8_t word[4];
+  __builtin_memcpy(word, &len, 4);
+  // literal from the record's start: the length word, and the term too unless a copy follows
+  if (p.head_lit) d = put_literal(d, word, 4, term, p.head_lit - 4);
+  const uint32_t back = 4 + prev_len;
+  for (uint32_t left = p.copy; left;) {
+    const uint32_t l = left < 64 ? left : 64;
+    *d++ = (uint8_t)(2 | ((l - 1) << 2));
+    *d++ = (uint8_t)back;
+    *d++ = (uint8_t)(back >> 8);
+    left -= l;
+  }
+  if (p.tail_lit) d = put_literal(d, word, 0, term + (len - p.tail_lit), p.tail_lit);
 }
 
 // data pages: every thread packs one group of eight indices
@@ -547,6 +658,146 @@ k_vpi_parts(const uint64_t* __restrict__ e, uint32_t n, const uint8_t* __restric
   }
 }
 
+// The parts column as snappy elements, by the rules of the pages of terms (k_enc_terms_packed): a row's text is the pieces of
+// its entries, the row before it in the file very often has the same pieces or begins with the same ones (the students of a
+// department carry the same predicates), so a row is a copy of the first bytes of the row before it and a literal of
+// the pieces that are left. Common bytes are counted in whole pieces. Per row: .x = pieces that are copied | bytes the
+// row's elements take before the literal's payload << 16, .y = common bytes | form << 30 (0: one literal, 1: same
+// length as the row before, 2: another length).
+__global__ void __launch_bounds__(256)
+k_vpi_rows_plan(const uint64_t* __restrict__ e, uint32_t n, const uint32_t* __restrict__ rowstart, uint32_t n_rows, const uint64_t* __restrict__ epos,
+                const uint64_t* __restrict__ etotal, int bits_code, int bits_term, const uint32_t* __restrict__ rowbase,
+                const uint32_t* __restrict__ name_off, uint32_t n_names, uint2* __restrict__ plan, uint32_t* __restrict__ packed) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const uint32_t a = rowstart[r], b = rowstart[r + 1];
+  const uint64_t end = b == n ? *etotal : epos[b];
+  const uint32_t len = (uint32_t)(end - epos[a] - 4);
+  const uint32_t q = (uint32_t)(e[a] >> (bits_code + bits_term));
+  uint32_t c = 0, m = 0, form = 0;
+  const bool first = (r - rowbase[q]) % (uint32_t)kParquetRowGroupRows == 0;
+  uint32_t prev_len = 0;
+  if (!first) {
+    const uint32_t pa = rowstart[r - 1];
+    prev_len = (uint32_t)(epos[a] - epos[pa] - 4);
+    if (4ull + prev_len <= 65535) {
+      const uint64_t code_mask = (1ull << bits_code) - 1;
+      const uint32_t most = (b - a) < (a - pa) ? (b - a) : (a - pa);
+      while (c < most && (e[a + c] & code_mask) == (e[pa + c] & code_mask)) {
+        uint32_t code = (uint32_t)(e[a + c] & code_mask);
+        if (code >= n_names) code -= n_names;
+        m += (c ? 2 : 1) + (name_off[code + 1] - name_off[code]);  // (comma,) role letter, name
+        ++c;
+      }
+      if (len == prev_len) form = 1;
+      else if (m >= 4) form = 2;
+      else { c = 0; m = 0; }
+    }
+  }
+  if (form == 0) { c = 0; m = 0; }
+  const uint32_t tail = len - m;
+  const uint32_t before_payload = form == 0 ? lit_bytes(4 + len) - (4 + len)
+                                : form == 1 ? copy_bytes(4 + m) + (lit_bytes(tail) - tail)
+                                            : 5 + copy_bytes(m) + (lit_bytes(tail) - tail);
+  plan[r] = make_uint2(c | (before_payload << 16), m | (form << 30));
+  packed[r] = before_payload + (form == 0 ? 4 + len : tail);
+}
+__device__ __forceinline__ uint8_t* put_literal_tag(uint8_t* d, uint32_t n) {
+  if (!n) return d;
+  const uint32_t v = n - 1;
+  if (v < 60) { *d++ = (uint8_t)(v << 2); return d; }
+  const int bytes = v < (1u << 8) ? 1 : v < (1u << 16) ? 2 : v < (1u << 24) ? 3 : 4;
+  *d++ = (uint8_t)((59 + bytes) << 2);
+  for (int i = 0; i < bytes; ++i) *d++ = (uint8_t)(v >> (8 * i));
+  return d;
+}
+__global__ void __launch_bounds__(256)
+k_vpi_parts_packed(const uint64_t* __restrict__ e, uint32_t n, const uint8_t* __restrict__ head, const uint32_t* __restrict__ rowidx,
+                   const uint32_t* __restrict__ rowstart, const uint64_t* __restrict__ epos, const uint64_t* __restrict__ etotal, int bits_code,
+                   int bits_term, const uint32_t* __restrict__ rowbase, const uint32_t* __restrict__ chunk0, const EncChunk* __restrict__ chunks,
+                   const uint8_t* __restrict__ names, const uint32_t* __restrict__ name_off, uint32_t n_names, const uint2* __restrict__ plan,
+                   const uint64_t* __restrict__ rpos, uint8_t* __restrict__ image) {
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t j = (uint32_t)(g >> 2), sub = (uint32_t)g & 3;
+  if (j >= n) return;
+  const uint64_t k = e[j];
+  const bool h = head[j] != 0;
+  const uint32_t r = rowidx[j] - (h ? 0 : 1);
+  const uint32_t q = (uint32_t)(k >> (bits_code + bits_term));
+  const uint32_t chunk = chunk0[q] + 2 * (uint32_t)((r - rowbase[q]) / kParquetRowGroupRows) + 1;
+  const uint2 pl = plan[r];
+  const uint32_t c = pl.x & 0xFFFFu, before_payload = pl.x >> 16, m = pl.y & 0x3FFFFFFFu, form = pl.y >> 30;
+  const uint32_t a = rowstart[r];
+  uint8_t* row = image + chunks[chunk].adj + rpos[r];
+  if (h && sub == 1) {  // the row's elements up to the literal's payload (the lane next to the one that writes the first piece)
+    const uint32_t nxt = rowstart[r + 1];
+    const uint32_t len = (uint32_t)((nxt == n ? *etotal : epos[nxt]) - epos[a] - 4);
+    uint8_t* d = row;
+    if (form == 0) {
+      d = put_literal_tag(d, 4 + len);
+    } else {
+      const uint32_t back = 4 + (uint32_t)(epos[a] - epos[rowstart[r - 1]] - 4);
+      if (form == 2) {
+        *d++ = (uint8_t)(3 << 2);  // a literal of four bytes: the length word
+        __builtin_memcpy(d, &len, 4);
+        d += 4;
+      }
+      for (uint32_t left = form == 1 ? 4 + m : m; left;) {
+        const uint32_t l = left < 64 ? left : 64;
+        *d++ = (uint8_t)(2 | ((l - 1) << 2));
+        *d++ = (uint8_t)back;
+        *d++ = (uint8_t)(back >> 8);
+        left -= l;
+      }
+      d = put_literal_tag(d, len - m);
+    }
+  }
+  if (j - a < c) return;  // this piece is part of what the row copies
+  uint32_t code = (uint32_t)(k & ((1ull << bits_code) - 1));
+  const char letter = code >= n_names ? 's' : 'o';
+  if (code >= n_names) code -= n_names;
+  // A row that is one literal carries its length word in the payload, in front of its first piece; otherwise the payload is
+  // the row's text from byte m on (the word has been written or copied before it).
+  uint8_t* dst;
+  uint32_t skip;  // bytes of the piece in front of the name
+  if (form == 0) {
+    dst = row + before_payload + (epos[j] - epos[a]);
+    skip = h ? 5 : 2;
+    if (sub == 0) {
+      if (h) {
+        const uint32_t nxt = rowstart[r + 1];
+        const uint32_t len = (uint32_t)((nxt == n ? *etotal : epos[nxt]) - epos[j] - 4);
+        __builtin_memcpy(dst, &len, 4);
+        dst[4] = (uint8_t)letter;
+      } else {
+        dst[0] = ',';
+        dst[1] = (uint8_t)letter;
+      }
+    }
+  } else {
+    const uint32_t at_text = h ? 0u : (uint32_t)(epos[j] - epos[a] - 4);  // where the piece begins in the row's text
+    dst = row + before_payload + (at_text - m);
+    skip = h ? 1 : 2;
+    if (sub == 0) {
+      if (h) dst[0] = (uint8_t)letter;
+      else { dst[0] = ','; dst[1] = (uint8_t)letter; }
+    }
+  }
+  dst += skip;
+  const uint8_t* src = names + name_off[code];
+  const uint32_t len = name_off[code + 1] - name_off[code];
+  if (len >= 16) {
+    for (uint32_t at0 = 16 * sub; at0 < len; at0 += 64) {
+      const uint32_t at = at0 + 16 <= len ? at0 : len - 16;
+      uint4 v;
+      __builtin_memcpy(&v, src + at, 16);
+      __builtin_memcpy(dst + at, &v, 16);
+    }
+  } else if (sub == 0) {
+    for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];
+  }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------
 struct LayoutFile {
   std::string path;
@@ -572,7 +823,9 @@ void upload(DevBuf<T>& d, DevPool& pool, const std::vector<T>& h, hipStream_t s)
 struct VpiState {  // the VP index of all partitions as sorted distinct (partition | term | code) entries
   uint32_t n = 0, n_rows = 0, n_names = 0;
   int bits_code = 0, bits_term = 0;
-  DevBuf<uint64_t> e, epos, etotal;
+  DevBuf<uint64_t> e, epos, etotal, rpos, rtotal;  // rpos: where every row's elements begin when the parts columns are packed
+  DevBuf<uint2> rplan;
+  bool parts_packed = false;
   DevBuf<uint8_t> head, names;
   DevBuf<uint32_t> rowidx, rowstart, rowbase, name_off, chunk0;
   std::vector<uint32_t> h_rowbase;
@@ -625,7 +878,10 @@ void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char
   if (const char* e = getenv("DX_WRITE_THREADS")) n_threads = (unsigned)std::max(1, atoi(e));
   tm.threads = (int)n_threads;
 
-  uint64_t ring_mib = 1024;
+  // 256 MiB: two 8 MiB pieces in flight per lane at sixteen lanes. Mapping the ring's pages costs the lanes' threads
+  // 49 ms per GiB and competes with everything else the host does meanwhile; with 1 GiB the call took 114 ms at LUBM-100,
+  // with 512 / 256 / 128 MiB 101 / 93 / 92 ms.
+  uint64_t ring_mib = 256;
   if (const char* e = getenv("DX_LAYOUT_RING_MIB")) ring_mib = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
   const unsigned ring_slots = (unsigned)std::max<uint64_t>(2ull * n_threads, (ring_mib << 20) / Lanes::kChunk);
   Lanes lanes(ctx->device, n_threads, ring_slots);  // the threads map the ring's pages while the GPU encodes
@@ -644,7 +900,8 @@ void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char
   // digits after "part-" (DAP.scala:427-428). One id per call stands in for the job's uuid.
   char job[64];
   snprintf(job, sizeof job, "%08x-dx00-4000-8000-%012llx", (unsigned)time(nullptr), (unsigned long long)(uintptr_t)ctx & 0xFFFFFFFFFFFFull);
-  auto part_file = [&](int k) { return "part-" + part_name(k) + "-" + job + "-c000.parquet"; };
+  const bool snappy = parquet_writer_uses_snappy();  // Spark's default codec and its file names, unless DX_PARQUET_CODEC=uncompressed
+  auto part_file = [&](int k) { return "part-" + part_name(k) + "-" + job + (snappy ? "-c000.snappy.parquet" : "-c000.parquet"); };
   {
     LayoutFile f;
     f.path = side + "/dictionary/offsets.bin";
@@ -899,18 +1156,36 @@ void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char
           hipLaunchKernelGGL(k_vpi_uri_entries, dim3(blocks_for(vp.n)), dim3(256), 0, s, vp.e.p, vp.n, vp.head.p, vp.rowidx.p, vp.bits_code, vp.bits_term,
                              vp.rowbase.p, vp.chunk0.p, id_bits, entries.p + n_sorted);
         upload(d_chunks, pool, chunks, s);
+        if (snappy && vp.n_rows && vp.n_names < 32768) {  // (a row's copied pieces are counted in 16 bits)
+          vp.parts_packed = true;
+          vp.rplan = DevBuf<uint2>(pool, vp.n_rows);
+          vp.rpos = DevBuf<uint64_t>(pool, vp.n_rows);
+          vp.rtotal = DevBuf<uint64_t>(pool, 1);
+          DevBuf<uint32_t> rlen(pool, vp.n_rows);
+          hipLaunchKernelGGL(k_vpi_rows_plan, dim3(blocks_for(vp.n_rows)), dim3(256), 0, s, vp.e.p, vp.n, vp.rowstart.p, vp.n_rows, vp.epos.p, vp.etotal.p, vp.bits_code,
+                             vp.bits_term, vp.rowbase.p, vp.name_off.p, vp.n_names, vp.rplan.p, rlen.p);
+          exclusive_scan_u32_u64(pool, rlen.p, vp.rpos.p, vp.n_rows, vp.rtotal.p, s);
+        }
       }
       const uint32_t n_chunks = (uint32_t)chunks.size();
       DevBuf<uint32_t> len4(pool, n_entries);
       DevBuf<uint64_t> dpos(pool, n_entries), dtotal(pool, 1);
       if (n_entries) hipLaunchKernelGGL(k_entry_lens, dim3(blocks_for(n_entries)), dim3(256), 0, s, entries.p, n_entries, (1ull << id_bits) - 1, d.pool_off.p, len4.p);
       exclusive_scan_u32_u64(pool, len4.p, dpos.p, n_entries, dtotal.p, s);
+      DevBuf<uint64_t> cpos, ctotal;  // snappy: where every entry's elements begin
+      if (snappy) {
+        cpos = DevBuf<uint64_t>(pool, n_entries);
+        ctotal = DevBuf<uint64_t>(pool, 1);
+        if (n_entries) hipLaunchKernelGGL(k_entry_packed_lens, dim3(blocks_for(n_entries)), dim3(256), 0, s, entries.p, n_entries, id_bits, d.pool.p, d.pool_off.p, len4.p);
+        exclusive_scan_u32_u64(pool, len4.p, cpos.p, n_entries, ctotal.p, s);
+      }
       DevBuf<ChunkSize> d_sizes(pool, n_chunks);
       std::vector<ChunkSize> sizes(n_chunks);
       uint32_t h_bad = 0;
       if (n_chunks) {
         hipLaunchKernelGGL(k_chunk_sizes, dim3(blocks_for(n_chunks)), dim3(256), 0, s, d_chunks.p, n_chunks, entries.p, n_sorted, id_bits, dpos.p, n_entries, dtotal.p,
-                           vp.rowstart.p, vp.epos.p, vp.n, vp.etotal.p, d_sizes.p);
+                           vp.rowstart.p, vp.epos.p, vp.n, vp.etotal.p, snappy ? cpos.p : nullptr, ctotal.p, vp.parts_packed ? vp.rpos.p : nullptr, vp.rtotal.p, vp.n_rows,
+                           d_sizes.p);
         DX_HIP(hipMemcpyAsync(sizes.data(), d_sizes.p, n_chunks * sizeof(ChunkSize), hipMemcpyDeviceToHost, s));
       }
       DX_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
@@ -934,6 +1209,8 @@ void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char
           c.num_values = chunks[k].n;
           if (chunks[k].kind == kChunkPlain || chunks[k].kind == kChunkParts) { c.plain = true; c.plain_bytes = sizes[k].bytes; }
           else { c.n_dict = sizes[k].count; c.dict_bytes = sizes[k].bytes; }
+          c.snappy = snappy;
+          c.terms_packed = snappy && (chunks[k].kind != kChunkParts || vp.parts_packed) ? sizes[k].packed_bytes : 0;
           in.push_back(c);
         }
         try {
@@ -1002,8 +1279,9 @@ void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char
             c.first = z.first;
             c.count = z.count;
             c.width = o.width;
-            if (c.kind == kChunkPlain || c.kind == kChunkParts) c.adj = f.at + o.data_at - z.start;
-            else { c.adj = f.at + o.dict_at - z.start; c.data_at = f.at + o.data_at; }
+            const uint64_t terms_from = snappy && (c.kind != kChunkParts || vp.parts_packed) ? z.packed_start : z.start;  // where the page's bytes begin in the list the kernels count in
+            if (c.kind == kChunkPlain || c.kind == kChunkParts) c.adj = f.at + o.data_at - terms_from;
+            else { c.adj = f.at + o.dict_at - terms_from; c.data_at = f.at + o.data_at; }
           }
           for (auto& h : plan.host) {
             small.push_back({blob.size(), f.at + h.first, h.second.size()});
@@ -1022,11 +1300,17 @@ void write_layout(dx_ctx* ctx, const char* base, const char* dataset, const char
       upload(d_word_tiles, pool, word_tiles, s);
       if (!small.empty()) hipLaunchKernelGGL(k_copy_small, dim3(blocks_for(small.size(), 4)), dim3(256), 0, s, d_small.p, (uint32_t)small.size(), d_blob.p, image.p);
       if (!word_tiles.empty()) hipLaunchKernelGGL(k_copy_words, dim3((unsigned)word_tiles.size()), dim3(256), 0, s, d_word_tiles.p, d_words.p, image.p);
-      if (n_entries)
+      if (n_entries && snappy)
+        hipLaunchKernelGGL(k_enc_terms_packed, dim3(blocks_for(n_entries)), dim3(256), 0, s, entries.p, n_entries, id_bits, d_chunks.p, cpos.p, d.pool.p, d.pool_off.p, image.p);
+      else if (n_entries)
         hipLaunchKernelGGL(k_enc_terms, dim3(blocks_for(4ull * n_entries)), dim3(256), 0, s, entries.p, n_entries, id_bits, d_chunks.p, dpos.p, d.pool.p, d.pool_off.p, image.p);
       if (!tiles.empty())
         hipLaunchKernelGGL(k_enc_indices, dim3((unsigned)tiles.size()), dim3(256), 0, s, d_tiles.p, d_chunks.p, d_pred_terms.p, entries.p, id_bits, image.p);
-      if (vp.n)
+      if (vp.n && vp.parts_packed)
+        hipLaunchKernelGGL(k_vpi_parts_packed, dim3(blocks_for(4ull * vp.n)), dim3(256), 0, s, vp.e.p, vp.n, vp.head.p, vp.rowidx.p, vp.rowstart.p, vp.epos.p,
+                           vp.etotal.p, vp.bits_code, vp.bits_term, vp.rowbase.p, vp.chunk0.p, d_chunks.p, vp.names.p, vp.name_off.p, vp.n_names, vp.rplan.p,
+                           vp.rpos.p, image.p);
+      else if (vp.n)
         hipLaunchKernelGGL(k_vpi_parts, dim3(blocks_for(4ull * vp.n)), dim3(256), 0, s, vp.e.p, vp.n, vp.head.p, vp.rowidx.p, vp.rowstart.p, vp.epos.p, vp.etotal.p,
                            vp.bits_code, vp.bits_term, vp.rowbase.p, vp.chunk0.p, d_chunks.p, vp.names.p, vp.name_off.p, vp.n_names, image.p);
       DX_HIP(hipGetLastError());

@@ -7,7 +7,7 @@
 // kRowGroupRows rows, REQUIRED BYTE_ARRAY columns annotated UTF8, per column chunk one dictionary page (PLAIN) and
 // one data page of bit-packed dictionary indices (the PLAIN_DICTIONARY encoding of parquet-mr's first-version
 // pages), Thrift compact footer. Terms repeat heavily inside a column, so the dictionary pages keep the files near
-// the size of Spark's own. Pages are uncompressed unless DX_PARQUET_CODEC=snappy asks for Spark's default codec
+// the size of Spark's own. Pages are snappy streams, Spark's default codec, unless DX_PARQUET_CODEC=uncompressed
 // (a third of the bytes on disk for LUBM's tables, and the encoding takes about twice as long).
 #include <algorithm>
 #include <cstdio>
@@ -117,9 +117,9 @@ void snappy_compress(const std::string& in, std::string& out) {
   }
 }
 
-bool snappy_pages() {
+bool snappy_pages() {  // Spark's default codec is this writer's too; DX_PARQUET_CODEC=uncompressed leaves the pages as they are
   const char* e = getenv("DX_PARQUET_CODEC");
-  return e && std::string(e) == "snappy";
+  return !(e && (std::string(e) == "uncompressed" || std::string(e) == "none"));
 }
 
 std::string page_header(int type, size_t size, size_t compressed_size, uint64_t num_values, bool dictionary_encoded) {
@@ -342,8 +342,32 @@ void ParquetWriter::close() {
 // The same file format as ParquetWriter's, uncompressed, for a caller that has the page bodies encoded on the GPU: from
 // the sizes of every column chunk's pages this lays the file out, writes everything that is not a page body (magic, page
 // headers, the bit width and run header in front of the packed indices, footer) and says where each body belongs.
+// A snappy stream begins with the length of what it unpacks to; a body that is sent as it is becomes one literal.
+static std::string snappy_preamble(uint64_t unpacked) {
+  Thrift v;
+  v.varint(unpacked);
+  return v.out;
+}
+static std::string snappy_literal_tag(uint64_t len) {  // the element header of a literal of len bytes (none for an empty one)
+  std::string out;
+  if (!len) return out;
+  const uint64_t n = len - 1;
+  if (n < 60) {
+    out.push_back((char)(n << 2));
+  } else {
+    const int bytes = n < (1u << 8) ? 1 : n < (1u << 16) ? 2 : n < (1u << 24) ? 3 : 4;
+    out.push_back((char)((59 + bytes) << 2));
+    for (int i = 0; i < bytes; ++i) out.push_back((char)(n >> (8 * i)));
+  }
+  return out;
+}
+
 PqFilePlan plan_parquet_file(const std::vector<std::string>& names, const std::vector<uint64_t>& group_rows, const std::vector<PqChunkIn>& chunks) {
   if (chunks.size() != names.size() * group_rows.size()) throw DxError(DX_E_INVAL, "parquet plan: chunk count differs from row groups x columns");
+  bool snappy = false;
+  for (const PqChunkIn& c : chunks) snappy |= c.snappy;
+  for (const PqChunkIn& c : chunks)
+    if (c.snappy != snappy) throw DxError(DX_E_INVAL, "parquet plan: one codec per file");
   PqFilePlan plan;
   plan.chunks.resize(chunks.size());
   uint64_t at = 0, cur_at = 0;
@@ -372,11 +396,26 @@ PqFilePlan plan_parquet_file(const std::vector<std::string>& names, const std::v
         if (in.plain_bytes >= (1ull << 31)) throw DxError(DX_E_RANGE, "data page of 2 GiB or more");
         m.dict_offset = -1;
         m.data_offset = (int64_t)at;
-        const std::string h = page_header(kDataPage, in.plain_bytes, in.plain_bytes, in.num_values, false);
-        host(h);
-        out.data_at = device(in.plain_bytes);
-        out.data_bytes = in.plain_bytes;
-        m.total_uncompressed = (int64_t)(h.size() + in.plain_bytes);
+        size_t header_bytes;
+        if (!snappy) {
+          const std::string h = page_header(kDataPage, in.plain_bytes, in.plain_bytes, in.num_values, false);
+          header_bytes = h.size();
+          host(h);
+          out.data_at = device(in.plain_bytes);
+          out.data_bytes = in.plain_bytes;
+        } else {
+          // the length it unpacks to, then either what the device packed or the body as one literal
+          const std::string pre = snappy_preamble(in.plain_bytes) + (in.terms_packed ? std::string() : snappy_literal_tag(in.plain_bytes));
+          const uint64_t from_device = in.terms_packed ? in.terms_packed : in.plain_bytes;
+          if (pre.size() + from_device >= (1ull << 31)) throw DxError(DX_E_RANGE, "data page of 2 GiB or more");
+          const std::string h = page_header(kDataPage, in.plain_bytes, pre.size() + from_device, in.num_values, false);
+          header_bytes = h.size();
+          host(h);
+          host(pre);
+          out.data_at = device(from_device);
+          out.data_bytes = from_device;
+        }
+        m.total_uncompressed = (int64_t)(header_bytes + in.plain_bytes);
         m.total_size = (int64_t)at - m.data_offset;
       } else {
         if (in.dict_bytes >= (1ull << 31)) throw DxError(DX_E_RANGE, "dictionary page of 2 GiB or more");
@@ -389,24 +428,42 @@ PqFilePlan plan_parquet_file(const std::vector<std::string>& names, const std::v
         const uint64_t body = prefix.size() + n8 * (uint64_t)width;
         if (body >= (1ull << 31)) throw DxError(DX_E_RANGE, "data page of 2 GiB or more");
         m.dict_offset = (int64_t)at;
-        const std::string hd = page_header(kDictionaryPage, in.dict_bytes, in.dict_bytes, in.n_dict, true);
-        host(hd);
-        out.dict_at = device(in.dict_bytes);
-        m.data_offset = (int64_t)at;
-        const std::string hp = page_header(kDataPage, body, body, in.num_values, true);
-        host(hp);
-        host(prefix);
+        size_t header_bytes;
+        if (!snappy) {
+          const std::string hd = page_header(kDictionaryPage, in.dict_bytes, in.dict_bytes, in.n_dict, true);
+          host(hd);
+          out.dict_at = device(in.dict_bytes);
+          m.data_offset = (int64_t)at;
+          const std::string hp = page_header(kDataPage, body, body, in.num_values, true);
+          host(hp);
+          host(prefix);
+          header_bytes = hd.size() + hp.size();
+        } else {
+          const std::string pre_d = snappy_preamble(in.dict_bytes) + (in.terms_packed || !in.dict_bytes ? std::string() : snappy_literal_tag(in.dict_bytes));
+          const uint64_t from_device = in.terms_packed ? in.terms_packed : in.dict_bytes;
+          const std::string hd = page_header(kDictionaryPage, in.dict_bytes, pre_d.size() + from_device, in.n_dict, true);
+          host(hd);
+          host(pre_d);
+          out.dict_at = device(from_device);
+          m.data_offset = (int64_t)at;
+          const std::string pre_p = snappy_preamble(body) + snappy_literal_tag(body);
+          const std::string hp = page_header(kDataPage, body, pre_p.size() + body, in.num_values, true);
+          host(hp);
+          host(pre_p);
+          host(prefix);
+          header_bytes = hd.size() + hp.size();
+        }
         out.width = (uint32_t)width;
         out.data_bytes = n8 * (uint64_t)width;
         out.data_at = device(out.data_bytes);
-        m.total_uncompressed = (int64_t)(hd.size() + in.dict_bytes + hp.size() + body);
+        m.total_uncompressed = (int64_t)(header_bytes + in.dict_bytes + body);
         m.total_size = (int64_t)at - m.dict_offset;
       }
       g.cols.push_back(m);
     }
     groups.push_back(std::move(g));
   }
-  host(footer_bytes(names, rows, groups, false));
+  host(footer_bytes(names, rows, groups, snappy));
   if (!cur.empty()) plan.host.emplace_back(cur_at, std::move(cur));
   plan.size = at;
   return plan;

@@ -341,7 +341,7 @@ void read_parquet_strings(const std::string& path, const std::vector<std::string
 
 // dx_parquet.cpp: files of REQUIRED string columns as the reference's Spark jobs write them (schemas of
 // utils/Types.scala:7-16). A column is given as term ids over a string pool, or as strings.
-bool parquet_writer_uses_snappy();  // DX_PARQUET_CODEC=snappy: pages compressed like Spark's own (file names say so too)
+bool parquet_writer_uses_snappy();  // pages are snappy streams like Spark's own (file names say so too) unless DX_PARQUET_CODEC=uncompressed
 class ParquetWriter {
  public:
   struct Column { const int64_t* ids; const std::string* strings; };
@@ -362,7 +362,16 @@ class ParquetWriter {
 // plain_bytes of length-prefixed values. The plan gives the file's size, every byte of it that is not a page body
 // (as (file offset, bytes) pieces in file order) and the file offsets of the bodies.
 constexpr uint64_t kParquetRowGroupRows = 1u << 20;
-struct PqChunkIn { uint64_t num_values = 0, n_dict = 0, dict_bytes = 0; bool plain = false; uint64_t plain_bytes = 0; };
+// snappy: the pages are snappy streams. The page of terms (a dictionary page, or a plain page that is a list of terms)
+// arrives from the device as `terms_packed` bytes of literals and copies, 0 for a plain page that the device writes
+// as it is (it then travels as one literal); the packed indices of a data page always travel as one literal.
+struct PqChunkIn {
+  uint64_t num_values = 0, n_dict = 0, dict_bytes = 0;
+  bool plain = false;
+  uint64_t plain_bytes = 0;
+  bool snappy = false;
+  uint64_t terms_packed = 0;
+};
 struct PqChunkOut { uint64_t dict_at = 0, data_at = 0, data_bytes = 0; uint32_t width = 0; };
 struct PqFilePlan { uint64_t size = 0; std::vector<std::pair<uint64_t, std::string>> host; std::vector<PqChunkOut> chunks; };
 // chunks: row group after row group, inside a group column after column

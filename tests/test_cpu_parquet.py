@@ -141,17 +141,22 @@ def test_native_parquet_writer_is_read_back_by_pyarrow(tmp_path):
     def term(k):
         return '"h\u00e9llo \U0001F642"@fr' if k == 1 else "<t%d>" % k + "x" * (k % 97)
     # "plan": the file laid out by plan_parquet_file from page sizes, the bodies dropped in (what the GPU encoder's host side does)
+    # "plan-snappy": the same with every page a snappy stream that carries its body as one literal; "plan-packed": the pages
+    # of terms packed by the rules the device follows (restated in the harness), read here by pyarrow's snappy
     for rows, codec in ((0, ""), (1, ""), (9, "snappy"), (3000000, ""), (3000000, "snappy"), (0, "snappy"), (0, "plan"), (1, "plan"), (9, "plan"),
-                        (2500000, "plan")):
+                        (2500000, "plan"), (0, "plan-snappy"), (1, "plan-snappy"), (2500000, "plan-snappy"), (1, "plan-packed"), (9, "plan-packed"),
+                        (2500000, "plan-packed")):
         out = str(tmp_path / ("t%d%s.parquet" % (rows, codec)))
-        r = subprocess.run([exe, out, str(rows), str(T)] + (["plan"] if codec == "plan" else []), capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, DX_PARQUET_CODEC="" if codec == "plan" else codec))
+        r = subprocess.run([exe, out, str(rows), str(T)] + ([codec] if codec.startswith("plan") else []), capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DX_PARQUET_CODEC=codec if codec == "snappy" else "uncompressed"))
         assert r.returncode == 0, r.stderr
         t = pq.read_table(out)
         assert t.column_names == ["_1", "_2", "parts"] and t.num_rows == rows
         md = pq.ParquetFile(out).metadata
         if rows:
-            assert md.row_group(0).column(0).compression == ("SNAPPY" if codec == "snappy" else "UNCOMPRESSED")
+            assert md.row_group(0).column(0).compression == ("SNAPPY" if codec in ("snappy", "plan-snappy", "plan-packed") else "UNCOMPRESSED")
+        if rows == 2500000 and codec == "plan-packed":  # "row<i>" after "row<i-1>", "<t<k>>xxx" after "<t<k-1>>xx": mostly copies
+            assert os.path.getsize(out) < 0.7 * os.path.getsize(str(tmp_path / "t2500000plan-snappy.parquet"))
         if rows == 3000000 and codec == "snappy":  # the terms of the test compress well; the bit-packed indices hardly
             assert os.path.getsize(out) < 0.7 * os.path.getsize(str(tmp_path / "t3000000.parquet"))
         assert md.num_row_groups >= (rows + (1 << 20) - 1) // (1 << 20) and md.num_rows == rows
@@ -242,7 +247,7 @@ def test_native_parquet_reader_reads_what_spark_style_writers_write(tmp_path):
     assert subprocess.run(cmd, capture_output=True, text=True, timeout=300).returncode == 0
     for codec in ("", "snappy"):
         own = str(tmp_path / ("own%s.parquet" % codec))
-        assert subprocess.run([wexe, own, "1200000", "5000"], capture_output=True, timeout=300, env=dict(os.environ, DX_PARQUET_CODEC=codec)).returncode == 0
+        assert subprocess.run([wexe, own, "1200000", "5000"], capture_output=True, timeout=300, env=dict(os.environ, DX_PARQUET_CODEC=codec or "uncompressed")).returncode == 0
         got, info = _read_with_harness(exe, own, ["_1", "_2", "parts"], tmp_path)
         t = pq.read_table(own)
         assert got == [[x.encode() for x in t[c].to_pylist()] for c in ("_1", "_2", "parts")]

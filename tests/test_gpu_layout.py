@@ -9,6 +9,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["uncompressed", "snappy"], autouse=True)
+def codec(request, monkeypatch):
+    """Every test of this file runs with plain pages and with the pages as snappy streams (the codec Spark writes by
+    default, and this writer too; DX_PARQUET_CODEC=uncompressed switches it off; the streams are made on the GPU as well)."""
+    monkeypatch.setenv("DX_PARQUET_CODEC", request.param)
+    return request.param
+
+
 def _layout_of(text, ci, n, tmp, name="ds"):
     from opus_amd.engine import Engine
     from oracle import dap_oracle
@@ -44,7 +52,8 @@ def test_edge_case_graphs(tmp_path):
 
 
 @pytest.mark.parametrize("batch_values,threads", [(None, None), (20000, 3), (1, 1)])
-def test_lubm1_in_one_batch_and_in_many(tmp_path, lubm1, monkeypatch, batch_values, threads):
+def test_lubm1_in_one_batch_and_in_many(tmp_path, lubm1, monkeypatch, batch_values, threads, codec):
+    import pyarrow.parquet as pq
     from parity_util import assert_layout_equals_oracle
     if batch_values:
         monkeypatch.setenv("DX_LAYOUT_BATCH_VALUES", str(batch_values))
@@ -54,6 +63,14 @@ def test_lubm1_in_one_batch_and_in_many(tmp_path, lubm1, monkeypatch, batch_valu
     on_disk = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(base) for f in fs if f.endswith((".parquet", ".dxcol", ".bin")))
     assert times["bytes"] == on_disk and times["threads"] == (threads or times["threads"])
     assert times["total_ms"] >= times["encode_ms"] > 0
+    # the files say which codec they carry, in their names as Spark's do and in their metadata; packed pages are smaller
+    parquet = [os.path.join(r, f) for r, _, fs in os.walk(base) for f in fs if f.endswith(".parquet")]
+    assert all(f.endswith(".snappy.parquet") == (codec == "snappy") for f in parquet)
+    biggest = max(parquet, key=os.path.getsize)
+    md = pq.ParquetFile(biggest).metadata.row_group(0).column(0)
+    assert md.compression == ("SNAPPY" if codec == "snappy" else "UNCOMPRESSED")
+    if codec == "snappy":
+        assert md.total_compressed_size < 0.6 * md.total_uncompressed_size
     # the id columns and the dictionary beside the Parquet files serve a fresh engine
     from opus_amd.engine import Engine
     e = Engine(0)

@@ -65,12 +65,12 @@ def test_native_import_of_a_layout_written_the_way_spark_writes_it(tmp_path, lub
     e = Engine(0)
     try:
         e.partition_text(lubm1["bytes"], lubm1["class_index"], 4)
+        monkeypatch.setenv("DX_PARQUET_CODEC", "uncompressed")
         e.write_layout(base, "lubm", str(tmp_path / "own"))
-        # the library's writer with Spark's default codec: same layout, the files say so by name, and they are smaller
-        monkeypatch.setenv("DX_PARQUET_CODEC", "snappy")
+        # the library's writer with Spark's default codec (its own default too): same layout, the files say so by name, and they are smaller
+        monkeypatch.delenv("DX_PARQUET_CODEC")
         os.makedirs(str(tmp_path / "own_snappy"))
         e.write_layout(str(tmp_path / "own_snappy") + "/", "lubm", str(tmp_path / "own_snappy"))
-        monkeypatch.delenv("DX_PARQUET_CODEC")
     finally:
         e.close()
     from parity_util import assert_layout_equals_oracle
