@@ -158,7 +158,7 @@ def file_leg(eng, arr, text, n_bytes, class_index, n_partitions):
                 "file_write_GBps": lt["bytes"] / max(lt["write_wall_ms"], 1e-6) / 1e6,
                 "end_to_end_triples_per_s": st.n_triples / (t_file + t_layout),
                 "note": "file in the page cache -> pinned staging (read and upload overlapped) -> HBM -> partitions; then the "
-                        "reference's layout on local disk: Parquet pages (dictionary pages, uncompressed) encoded on the GPU, the "
+                        "reference's layout on local disk: Parquet pages (dictionary pages, snappy streams like Spark's) encoded on the GPU, the "
                         "files' bytes copied to pinned host memory piece by piece while host threads write the pieces that have "
                         "landed (device_to_host and file_write overlap); end_to_end = triples / (partition_file + write_layout)"}
     finally:
