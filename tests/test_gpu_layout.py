@@ -43,6 +43,17 @@ def test_edge_case_graphs(tmp_path):
     for name in ("appendix_c.json", "hand_derived_2.json"):   # the hand-derived examples as files too
         g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
         cases["golden " + name] = (g["instances"], g["class_index"], g["n_partitions"])
+    # pages whose records do what the packing rules branch on: terms of 64 KiB and more (nothing can reach back over them),
+    # neighbours of equal and of different length with long and with short common beginnings, equal rows of predicates
+    T = "<http://www.w3.org/1999/02/22-rdf-syntax-ns#type>"
+    long_a, long_b = "x" * 70000, "x" * 69990 + "y" * 10
+    lines = ["<http://e/s%03d> %s <A> ." % (i, T) for i in range(40)]
+    lines += ["<http://e/s%03d> <http://e/knows> <http://e/s%03d> ." % (i, (i * 7 + 1) % 40) for i in range(40)]
+    lines += ['<http://e/s000> <http://e/note> "%s" .' % long_a, '<http://e/s001> <http://e/note> "%s" .' % long_b,
+              '<http://e/s002> <http://e/note> "%s" .' % ("p" * 200), '<http://e/s003> <http://e/note> "%s" .' % ("p" * 199 + "q"),
+              '<http://e/s004> <http://e/note> "%s" .' % ("p" * 130), '<http://e/s005> <http://e/note> "" .', '<http://e/s006> <http://e/note> "ab" .',
+              '<http://e/s007> <http://e/note> "abc" .']
+    cases["records the packing rules branch on"] = ("\n".join(lines) + "\n", "<A>\t0,1\n", 2)
     for i, name in enumerate(sorted(cases)):
         text, ci, n = cases[name]
         d = tmp_path / ("c%d" % i)
