@@ -199,6 +199,12 @@ int dx_unload_all(dx_ctx* ctx);
 /* Replaces executeFinalQuery -> spark.sqlContext.sql(query) (QueryProcessor.scala:184-195) followed by
  * result.count. sql is one statement of the translated-query grammar (QueryTranslator.scala:363-392, 417-543). */
 int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out);
+/* The query map of a translated file that holds several statements (QueryProcessor.scala:73-88 reads them, :184-195
+ * executes each and folds the results with customJoin, :197-208: an inner join on the output columns two results share,
+ * commonColumns :276-278, or a cross join when they share none). Same result handle as dx_query: the count of the joined
+ * result (what the reference's timed result.count returns), or its bindings; columns in Spark's order for such a join
+ * (shared, left, right). The statements are joined in the order given. With n == 1 this is dx_query. */
+int dx_query_joined(dx_ctx* ctx, const char* const* statements, int n, int mode, dx_result** out);
 /* No counterpart in the reference. The count of dx_query(sql, DX_QUERY_COUNT) for callers that cannot allocate
  * device memory while they run: code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc. The statement's device scratch (resolved constants, row counters, intermediate relations, hash-join

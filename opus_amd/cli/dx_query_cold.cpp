@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
   std::ifstream f(query_path);
   if (!f) { fprintf(stderr, "dx-query-cold: cannot open %s\n", query_path.c_str()); return 1; }
   std::string line;
-  std::vector<std::string> partitions, statements;
+  std::vector<std::string> partitions, statements, keys_seen;  // the reference's query map keeps one statement per key
   int tp = -1;
   while (std::getline(f, line)) {  // :65-80
     if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -92,11 +92,15 @@ int main(int argc, char** argv) {
     else if (line.rfind("partitions", 0) == 0) { auto t = split(line, ' '); partitions = t.size() > 1 ? split(t[1], ',') : std::vector<std::string>(); }
     else if (line.rfind(">>>>>", 0) != 0) {
       const size_t sp = line.find(' ');
-      statements.push_back(sp == std::string::npos ? "" : line.substr(sp + 1));
+      const std::string key = line.substr(0, sp), sql = sp == std::string::npos ? "" : line.substr(sp + 1);
+      size_t at = 0;
+      while (at < keys_seen.size() && keys_seen[at] != key) ++at;
+      if (at == keys_seen.size()) { keys_seen.push_back(key); statements.push_back(sql); }
+      else statements[at] = sql;
     }
   }
-  if (statements.size() != 1) {
-    fprintf(stderr, "dx-query-cold: %s holds %zu statements; the translator writes exactly one\n", name.c_str(), statements.size());
+  if (statements.empty()) {
+    fprintf(stderr, "dx-query-cold: %s holds no statement\n", name.c_str());
     return 1;
   }
 
@@ -116,7 +120,11 @@ int main(int argc, char** argv) {
   }
   const auto t1 = std::chrono::steady_clock::now();
   dx_result* r = nullptr;
-  if (dx_query(ctx, statements[0].c_str(), DX_QUERY_BINDINGS, &r) != DX_OK) return fail("query");
+  {  // one statement, or several whose results are joined on the columns they share (executeFinalQuery / customJoin)
+    std::vector<const char*> sqls;
+    for (const auto& q : statements) sqls.push_back(q.c_str());
+    if (dx_query_joined(ctx, sqls.data(), (int)sqls.size(), DX_QUERY_BINDINGS, &r) != DX_OK) return fail("query");
+  }
   const uint64_t rows = dx_result_count(r);
   const int cols = dx_result_columns(r);
   std::vector<int64_t> ids(rows * (uint64_t)cols + 1);

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cstring>
 #include <ctime>
 #include <fstream>
 #include <map>
@@ -19,6 +20,7 @@
 #include <unordered_map>
 
 #include "dx_device.h"
+#include "dx_sql.h"
 #include "dx_state.h"
 
 namespace dx {
@@ -254,7 +256,7 @@ void dx_free(dx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   rccl_comm_destroy(ctx);
-  ctx->catalog.clear();
+  ctx->catalog.clear(); ctx->union_tables.clear();
   ctx->part = PartitionState();
   ctx->dict = Dictionary();
   ctx->qws.reset();
@@ -962,7 +964,7 @@ bool ends_with(const std::string& s, const char* suffix) {
 }
 
 void install_dictionary(dx_ctx* ctx, const char* bytes, const uint64_t* offsets, uint64_t n_terms) {
-  ctx->catalog.clear();
+  ctx->catalog.clear(); ctx->union_tables.clear();
   ctx->table_stats.clear();
   ctx->imported.clear();
   ctx->part = PartitionState();
@@ -1057,7 +1059,7 @@ int dx_open_dataset(dx_ctx* ctx, const char* base, const char* dataset, int n_pa
       for (size_t i = 0; ok && i < n; ++i) ok = o[i] <= o[i + 1];
       if (!ok) throw DxError(DX_E_IO, "corrupt dictionary: offsets.bin does not describe terms.bin");
     }
-    ctx->catalog.clear();
+    ctx->catalog.clear(); ctx->union_tables.clear();
     ctx->table_stats.clear();
     ctx->imported.clear();
     ctx->part = PartitionState();
@@ -1503,7 +1505,7 @@ int dx_set_table_stats(dx_ctx* ctx, const char* partition_key, const uint64_t in
 }
 
 int dx_unload_all(dx_ctx* ctx) {
-  return guard(ctx, [&] { ctx->catalog.clear(); });
+  return guard(ctx, [&] { ctx->catalog.clear(); ctx->union_tables.clear(); });
 }
 
 // ---- queries -----------------------------------------------------------------------------------------
@@ -1512,6 +1514,21 @@ int dx_query(dx_ctx* ctx, const char* sql, int mode, dx_result** out) {
     if (!sql || !out) throw DxError(DX_E_INVAL, "null argument");
     if (mode != DX_QUERY_COUNT && mode != DX_QUERY_BINDINGS) throw DxError(DX_E_INVAL, "unknown query mode");
     *out = ctx->comm.world > 1 ? run_query_sharded(ctx, sql, mode) : run_query(ctx, sql, mode);
+  });
+}
+
+int dx_query_joined(dx_ctx* ctx, const char* const* statements, int n, int mode, dx_result** out) {
+  return guard(ctx, [&] {
+    if (!statements || !out || n < 1) throw DxError(DX_E_INVAL, "null argument or no statement");
+    if (mode != DX_QUERY_COUNT && mode != DX_QUERY_BINDINGS) throw DxError(DX_E_INVAL, "unknown query mode");
+    std::string text;
+    for (int i = 0; i < n; ++i) {
+      if (!statements[i]) throw DxError(DX_E_INVAL, "null statement");
+      if (strchr(statements[i], kStatementSeparator)) throw DxError(DX_E_MALFORMED, "SQL: control character in a statement");
+      if (i) text.push_back(kStatementSeparator);
+      text += statements[i];
+    }
+    *out = ctx->comm.world > 1 ? run_query_sharded(ctx, text, mode) : run_query(ctx, text, mode);
   });
 }
 

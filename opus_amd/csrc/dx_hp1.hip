@@ -2183,7 +2183,82 @@ k_unpack_distinct_pairs(const uint64_t* __restrict__ in, const uint8_t* __restri
   s[pos[i]] = (int64_t)(in[i] >> 32);
   o[pos[i]] = (int64_t)(in[i] & 0xFFFFFFFFu);
 }
+// rows of one UNION arm that pass its constants, as packed (first column, second column) words behind *count
+__global__ void __launch_bounds__(256)
+k_union_pairs(const int64_t* __restrict__ s, const int64_t* __restrict__ o, uint64_t n, int has_s, int64_t want_s, int has_o, int64_t want_o,
+              int src_a, int src_b, uint64_t* __restrict__ out, unsigned long long* __restrict__ count) {
+  __shared__ uint32_t lds[8];
+  __shared__ unsigned long long base_s;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n; i0 += (uint64_t)gridDim.x * 256) {  // block-uniform
+    const uint64_t i = i0 + threadIdx.x;
+    bool take = i < n;
+    int64_t vs = 0, vo = 0;
+    if (take) {
+      vs = s[i];
+      vo = o[i];
+      take = (!has_s || vs == want_s) && (!has_o || vo == want_o);
+    }
+    uint32_t total;
+    const uint32_t before = block_excl_scan_256<uint32_t>(take ? 1u : 0u, lds, total);
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    if (take) {
+      const uint64_t a = src_a < 0 ? 0 : (uint64_t)(src_a == 0 ? vs : vo), b = src_b < 0 ? 0 : (uint64_t)(src_b == 0 ? vs : vo);
+      out[base_s + before] = (a << 32) | (uint32_t)b;
+    }
+    __syncthreads();
+  }
+}
 }  // namespace
+
+const CatalogTable* distinct_union_of(dx_ctx* ctx, const std::vector<UnionSource>& arms, const std::string& signature) {
+  auto hit = ctx->union_tables.find(signature);
+  if (hit != ctx->union_tables.end()) return hit->second.get();
+  if (ctx->dict.n_terms >= (1ull << 32)) throw DxError(DX_E_RANGE, "dictionary too large for a duplicate-free UNION");
+  hipStream_t s = ctx->stream;
+  DevPool& pool = ctx->pool;
+  uint64_t most = 0;
+  for (const UnionSource& a : arms) most += a.t->rows;
+  if (most >= (1ull << 32)) throw DxError(DX_E_RANGE, "UNION arms of 2^32 rows or more");
+  DevBuf<uint64_t> keys(pool, std::max<uint64_t>(most, 1));
+  DevBuf<unsigned long long> count(pool, 1);
+  DX_HIP(hipMemsetAsync(count.p, 0, 8, s));
+  for (const UnionSource& a : arms)
+    if (a.t->rows)
+      hipLaunchKernelGGL(k_union_pairs, dim3(std::min<unsigned>(blocks(a.t->rows), 4096u)), dim3(256), 0, s, a.t->s, a.t->o, a.t->rows, a.has_s ? 1 : 0, a.want_s,
+                         a.has_o ? 1 : 0, a.want_o, a.src_a, a.src_b, keys.p, count.p);
+  unsigned long long n64 = 0;
+  DX_HIP(hipMemcpyAsync(&n64, count.p, 8, hipMemcpyDeviceToHost, s));
+  DX_HIP(hipStreamSynchronize(s));
+  const uint32_t n = (uint32_t)n64;
+  auto v = std::make_unique<CatalogTable>();
+  v->view = "(UNION, every row once)";
+  uint32_t kept = 0;
+  if (n) {
+    radix_sort_u64(pool, keys, n, 32 + bits_for(ctx->dict.n_terms ? ctx->dict.n_terms : 1), s);
+    DevBuf<uint8_t> flag(pool, n);
+    DevBuf<uint32_t> pos(pool, n), d_total(pool, 1);
+    hipLaunchKernelGGL(k_flag_distinct<uint64_t>, dim3(blocks(n)), dim3(256), 0, s, keys.p, n, flag.p);
+    exclusive_scan_u8_u32(pool, flag.p, pos.p, n, d_total.p, s);
+    DX_HIP(hipMemcpyAsync(&kept, d_total.p, 4, hipMemcpyDeviceToHost, s));
+    DX_HIP(hipStreamSynchronize(s));
+    v->own_s = DevBuf<int64_t>(pool, kept);
+    v->own_o = DevBuf<int64_t>(pool, kept);
+    hipLaunchKernelGGL(k_unpack_distinct_pairs, dim3(blocks(n)), dim3(256), 0, s, keys.p, flag.p, pos.p, n, v->own_s.p, v->own_o.p);
+    DX_HIP(hipStreamSynchronize(s));
+  } else {
+    v->own_s = DevBuf<int64_t>(pool, 1);
+    v->own_o = DevBuf<int64_t>(pool, 1);
+  }
+  v->rows = kept;
+  v->s = v->own_s.p;
+  v->o = v->own_o.p;
+  v->slices.push_back({v->s, v->o, kept});
+  v->stats_pending = true;
+  const CatalogTable* out = v.get();
+  ctx->union_tables.emplace(signature, std::move(v));
+  return out;
+}
 
 const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t) {
   if (!t.several_sources || t.rows < 2) return &t;
@@ -2367,7 +2442,7 @@ static void run_partition_body(dx_ctx* ctx, const uint8_t* text, uint64_t n_byte
   DevPool& pool = ctx->pool;
   if (nparts < 1 || nparts > DX_MAX_PARTITIONS) throw DxError(DX_E_INVAL, "n_partitions must be in [1, 64]");
   if (n_bytes >= (1ull << (64 - kRepLenBits))) throw DxError(DX_E_RANGE, "input larger than 1 TiB");
-  ctx->catalog.clear();
+  ctx->catalog.clear(); ctx->union_tables.clear();
   ctx->table_stats.clear();
   ctx->imported.clear();
   ctx->part = PartitionState();

@@ -872,7 +872,8 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true, uint64_
     for (int c = 0; c < r.ncols; ++c)
       for (int c2 = 0; c2 < c; ++c2)
         if (r.cls[c] == r.cls[c2]) throw DxError(DX_E_UNSUPPORTED, "SQL: join condition between two columns of one sub-select");
-    double sel = 1.0;
+    struct Cand { PlanRel::Arm a; bool has_s, has_o; std::string s_const, o_const; };
+    std::vector<Cand> cands;
     std::vector<std::string> seen;
     for (const SqlArm& arm : sub.arms) {
       std::string sig = arm.table + "\x02" + (arm.has_s ? arm.s_const : "\x03") + "\x02" + (arm.has_o ? arm.o_const : "\x03");
@@ -886,12 +887,93 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true, uint64_
       if (sub.arms.size() > 1 && !may_allocate && it->second.several_sources && it->second.rows >= 2 && !it->second.distinct_view)
         throw DxError(DX_E_INVAL, "table " + it->second.view + " has no duplicate-free copy yet: run the statement through dx_query once");
       a.t = sub.arms.size() > 1 ? distinct_view_of(ctx, it->second) : &it->second;
-      if (arm.has_s) a.fs = add_const(arm.s_const);
-      if (arm.has_o) a.fo = add_const(arm.o_const);
       for (int c = 0; c < r.ncols; ++c) {
         a.src[c] = arm.proj[c].src;
         if (a.src[c] == 2) { a.src_ci[c] = -1; a.src_val[c] = add_virtual(arm.proj[c].constant); }
       }
+      cands.push_back({a, arm.has_s, arm.has_o, arm.s_const, arm.o_const});
+    }
+    // SQL's UNION returns every row once. Arms that project different constants cannot produce the same row, and an arm
+    // whose row fixes both columns of its (duplicate-free) table produces no row twice: that is every UNION the
+    // translator writes ('<directory>' AS P in each arm). Arms that can coincide -- the same constants, or none, over
+    // different tables or filters; an arm that leaves a column of its table out -- are replaced, group by group, by the
+    // duplicate-free table of their rows (distinct_union_of), which then is an arm like any other.
+    if (sub.arms.size() > 1) {
+      std::vector<std::vector<size_t>> groups;
+      for (size_t i = 0; i < cands.size(); ++i) {
+        bool placed = false;
+        for (auto& g : groups) {
+          const Cand& h = cands[g[0]];
+          bool same = true;
+          for (int c = 0; c < r.ncols; ++c)
+            same &= (h.a.src[c] == 2) == (cands[i].a.src[c] == 2) && (h.a.src[c] != 2 || h.a.src_val[c] == cands[i].a.src_val[c]);
+          if (same) { g.push_back(i); placed = true; break; }
+        }
+        if (!placed) groups.push_back({i});
+      }
+      std::vector<Cand> replaced;
+      for (const auto& g : groups) {
+        auto fixes_both = [&](const Cand& x) {
+          bool fs = x.has_s, fo = x.has_o;
+          for (int c = 0; c < r.ncols; ++c) { fs |= x.a.src[c] == 0; fo |= x.a.src[c] == 1; }
+          return fs && fo;
+        };
+        if (g.size() == 1 && fixes_both(cands[g[0]])) { replaced.push_back(cands[g[0]]); continue; }
+        if (ctx->comm.world > 1) throw DxError(DX_E_UNSUPPORTED, "SQL: UNION arms whose rows can coincide, on several GPUs");
+        std::string signature;
+        std::vector<UnionSource> sources;
+        std::vector<std::string> lookups;
+        for (size_t i : g) {
+          const Cand& x = cands[i];
+          UnionSource u;
+          u.t = x.a.t;
+          u.has_s = x.has_s; u.has_o = x.has_o;
+          for (int c = 0; c < r.ncols; ++c)
+            if (x.a.src[c] != 2) (u.src_a < 0 ? u.src_a : u.src_b) = x.a.src[c];
+          signature += x.a.t->view + "\x02" + std::to_string((uintptr_t)x.a.t) + "\x02" + (x.has_s ? x.s_const : "\x03") + "\x02" + (x.has_o ? x.o_const : "\x03") +
+                       "\x02" + std::to_string(u.src_a) + std::to_string(u.src_b) + "\x01";
+          if (x.has_s) lookups.push_back(x.s_const);
+          if (x.has_o) lookups.push_back(x.o_const);
+          sources.push_back(u);
+        }
+        const CatalogTable* table = nullptr;
+        auto known = ctx->union_tables.find(signature);
+        if (known != ctx->union_tables.end()) {
+          table = known->second.get();
+        } else {
+          if (!may_allocate) throw DxError(DX_E_INVAL, "a UNION of this statement has no duplicate-free copy yet: run the statement through dx_query once");
+          std::vector<int64_t> ids(lookups.size());
+          if (!lookups.empty()) {
+            std::string bytes;
+            std::vector<uint64_t> off{0};
+            for (const std::string& t : lookups) { bytes += t; off.push_back(bytes.size()); }
+            dict_lookup(ctx, bytes.data(), off.data(), lookups.size(), ids.data());
+          }
+          size_t at = 0;
+          for (size_t k = 0; k < g.size(); ++k) {
+            if (sources[k].has_s) sources[k].want_s = ids[at++];
+            if (sources[k].has_o) sources[k].want_o = ids[at++];
+          }
+          table = distinct_union_of(ctx, sources, signature);
+        }
+        if (table->stats_pending) {
+          if (!may_allocate) throw DxError(DX_E_INVAL, "a UNION of this statement has no statistics yet: run the statement through dx_query once");
+          table_statistics(ctx, {const_cast<CatalogTable*>(table)});
+        }
+        Cand y = cands[g[0]];
+        y.a.t = table;
+        y.has_s = y.has_o = false;
+        int next_col = 0;
+        for (int c = 0; c < r.ncols; ++c)
+          if (y.a.src[c] != 2) y.a.src[c] = next_col++;
+        replaced.push_back(y);
+      }
+      cands = std::move(replaced);
+    }
+    for (const Cand& cd : cands) {
+      PlanRel::Arm a = cd.a;
+      if (cd.has_s) a.fs = add_const(cd.s_const);
+      if (cd.has_o) a.fo = add_const(cd.o_const);
       r.arms.push_back(a);
       r.rows_upper += a.t->rows;
       // uniform-frequency estimate from the table's row and distinct counts (gathered when it was loaded)
@@ -901,15 +983,14 @@ Plan make_plan(dx_ctx* ctx, const SqlQuery& q, bool may_allocate = true, uint64_
                    dob = (double)std::max<uint64_t>(t.has_plan_stats ? t.plan_distinct_o : t.distinct_o, 1);
       r.rows_plan += n;
       double rows = n;
-      if (arm.has_s) rows /= ds;
-      if (arm.has_o) rows /= dob;
+      if (cd.has_s) rows /= ds;
+      if (cd.has_o) rows /= dob;
       rows = std::max(rows, n > 0 ? 1.0 : 0.0);
       r.est += rows;
       for (int c = 0; c < r.ncols; ++c) {
-        const double d = a.src[c] == 0 ? (arm.has_s ? 1.0 : std::min(ds, rows)) : a.src[c] == 1 ? (arm.has_o ? 1.0 : std::min(dob, rows)) : 1.0;
-        r.dist[c] = (&arm == &sub.arms[0]) ? d : r.dist[c] + d;
+        const double d = a.src[c] == 0 ? (cd.has_s ? 1.0 : std::min(ds, rows)) : a.src[c] == 1 ? (cd.has_o ? 1.0 : std::min(dob, rows)) : 1.0;
+        r.dist[c] = (&cd == &cands[0]) ? d : r.dist[c] + d;
       }
-      (void)sel;
     }
     rels.push_back(std::move(r));
   }

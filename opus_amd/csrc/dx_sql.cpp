@@ -148,7 +148,63 @@ SqlSub parse_sub(Lexer& lx) {
 
 }  // namespace
 
+// The statements of one query file, joined the way QueryProcessor.executeFinalQuery joins their results
+// (query_processor/QueryProcessor.scala:184-208, 276-278): left to right, each time on the output columns the two
+// sides share (Dataset.join(right, commonCols, "inner")), or as a cross product when they share none. A statement's
+// result is a bag and so is the join, so the join of the results equals ONE statement over all sub-selects of all
+// statements with an equality added for every shared output column; that statement is what this returns. Its output
+// columns come in Spark's order: the shared ones, then the left side's others, then the right side's others.
+static SqlQuery join_statements(const std::vector<SqlQuery>& parts) {
+  SqlQuery acc;
+  for (size_t k = 0; k < parts.size(); ++k) {
+    SqlQuery r = parts[k];
+    const std::string prefix = "q" + std::to_string(k) + "_";  // the statements number their sub-selects alike (tab0, tab1, ...)
+    for (SqlSub& sub : r.subs) sub.alias = prefix + sub.alias;
+    for (SqlQuery::Item& it : r.select) it.alias = prefix + it.alias;
+    for (SqlQuery::Cond& c : r.conds) { c.a_alias = prefix + c.a_alias; c.b_alias = prefix + c.b_alias; }
+    if (k == 0) { acc = std::move(r); continue; }
+    std::vector<SqlQuery::Item> shared, left_only, right_only;
+    for (const SqlQuery::Item& l : acc.select) {
+      const SqlQuery::Item* same = nullptr;
+      for (const SqlQuery::Item& x : r.select)
+        if (x.name == l.name) same = &x;
+      if (same) {
+        shared.push_back(l);
+        acc.conds.push_back({l.alias, l.col, same->alias, same->col});
+      } else {
+        left_only.push_back(l);
+      }
+    }
+    for (const SqlQuery::Item& x : r.select) {
+      bool in_left = false;
+      for (const SqlQuery::Item& l : acc.select) in_left |= l.name == x.name;
+      if (!in_left) right_only.push_back(x);
+    }
+    acc.select = shared;
+    acc.select.insert(acc.select.end(), left_only.begin(), left_only.end());
+    acc.select.insert(acc.select.end(), right_only.begin(), right_only.end());
+    for (SqlSub& sub : r.subs) acc.subs.push_back(std::move(sub));
+    for (SqlQuery::Cond& c : r.conds) acc.conds.push_back(std::move(c));
+  }
+  return acc;
+}
+
+static SqlQuery parse_one(const std::string& text);
+
 SqlQuery parse_sql(const std::string& text) {
+  if (text.find(kStatementSeparator) == std::string::npos) return parse_one(text);
+  std::vector<SqlQuery> parts;
+  size_t at = 0;
+  for (;;) {
+    const size_t end = text.find(kStatementSeparator, at);
+    parts.push_back(parse_one(text.substr(at, end == std::string::npos ? std::string::npos : end - at)));
+    if (end == std::string::npos) break;
+    at = end + 1;
+  }
+  return join_statements(parts);
+}
+
+static SqlQuery parse_one(const std::string& text) {
   Lexer lx(text);
   SqlQuery q;
   lx.expect_kw("SELECT");

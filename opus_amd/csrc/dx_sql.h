@@ -26,6 +26,9 @@ struct SqlQuery {
   std::vector<Cond> conds;
 };
 
+// Several statements in one text are separated by this character (dx_query_joined puts them together that way); what
+// comes back is then the one statement that joins their results as the reference's customJoin does.
+constexpr char kStatementSeparator = '\x1e';
 // Throws DxError(DX_E_MALFORMED / DX_E_UNSUPPORTED).
 SqlQuery parse_sql(const std::string& text);
 

@@ -131,6 +131,16 @@ struct CatalogTable {
   const int64_t* o = nullptr;
 };
 
+// One arm of a UNION as far as its rows go: the table, the constants its columns are compared with (ids; -1: a constant the
+// dictionary does not hold, which matches nothing), and which of its columns become the first and the second output
+// column (0 = s, 1 = o, -1 = none).
+struct UnionSource {
+  const CatalogTable* t = nullptr;
+  bool has_s = false, has_o = false;
+  int64_t want_s = 0, want_o = 0;
+  int src_a = -1, src_b = -1;
+};
+
 }  // namespace dx
 
 namespace dx { struct RcclComm; struct SqlQuery; }
@@ -162,6 +172,9 @@ struct dx_ctx {
   void* file_stage[dx::kFileStages] = {};          // pinned buffers dx_partition_file streams a file through
   hipEvent_t file_stage_ev[dx::kFileStages] = {};
   void* q_counters = nullptr;           // device: a statement's row counters and its last-block ticket, zero between statements
+  // duplicate-free results of groups of UNION arms that may hold a row more than once (see distinct_union_of), by the
+  // group's description; emptied whenever the catalogue is
+  std::unordered_map<std::string, std::unique_ptr<dx::CatalogTable>> union_tables;
   std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
   // Statements come again: the parsed form is kept per text, and the join order the search found per (text, numbers the
   // search looked at), so a repeated statement over tables with the same statistics skips both (DX_NO_PLAN_CACHE=1: never).
@@ -394,6 +407,9 @@ void dict_build_table(dx_ctx* ctx);  // (re)builds ht_* from pool/pool_off
 void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables);
 // the table without repeated rows (built on first use), or the table itself when it has one source
 const CatalogTable* distinct_view_of(dx_ctx* ctx, CatalogTable& t);
+// The rows the arms produce together, every row once, as a table of its own (first output column as s, second as o;
+// a missing one is 0 throughout): what SQL's UNION makes of arms whose rows can coincide. Kept under `signature`.
+const CatalogTable* distinct_union_of(dx_ctx* ctx, const std::vector<UnionSource>& arms, const std::string& signature);
 // dx_measures.hip
 void run_measures(dx_ctx* ctx, dx_measure_sizes* out);
 // dx_hp2.hip

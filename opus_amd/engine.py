@@ -29,7 +29,7 @@ EXPORTS = [
     "dx_part_fetch", "dx_table_count", "dx_table_info_at", "dx_table_fetch", "dx_node_index_rows",
     "dx_node_index_fetch", "dx_vp_index_rows", "dx_vp_index_fetch", "dx_instance_graph_sizes",
     "dx_instance_graph_fetch", "dx_part_write_layout", "dx_layout_times", "dx_open_dataset", "dx_load_table", "dx_unload_all",
-    "dx_query", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
+    "dx_query", "dx_query_joined", "dx_result_count", "dx_result_columns", "dx_result_column_name", "dx_result_fetch_ids",
     "dx_result_virtual_term", "dx_result_plan", "dx_result_device_ms", "dx_result_free",
     "dx_dictionary_load", "dx_load_table_ids", "dx_set_comm", "dx_declare_remote_table", "dx_table_stats", "dx_set_table_stats", "dx_result_local_rows",
     "dx_measures_compute", "dx_measures_classes", "dx_measures_cc", "dx_measures_write", "dx_load_tables",
@@ -118,6 +118,7 @@ def load_library():
         "dx_load_tables": (c_int, [c_void_p, POINTER(c_char_p), c_int, u64p]),
         "dx_unload_all": (c_int, [c_void_p]),
         "dx_query": (c_int, [c_void_p, c_char_p, c_int, POINTER(c_void_p)]),
+        "dx_query_joined": (c_int, [c_void_p, POINTER(c_char_p), c_int, c_int, POINTER(c_void_p)]),
         "dx_query_count_noalloc": (c_int, [c_void_p, c_char_p, u64p]),
         "dx_allocator_stats": (c_int, [c_void_p, u64p, u64p]),
         "dx_result_count": (c_uint64, [c_void_p]),
@@ -473,6 +474,16 @@ class Engine:
         n = c_uint64(0)
         self._check(self.lib.dx_query_count_noalloc(self.ctx, sql.encode("utf-8", "surrogateescape"), byref(n)))
         return n.value
+
+    def query_joined(self, statements, mode: int = DX_QUERY_COUNT) -> QueryResult:
+        """The statements of one translated file executed and their results joined left to right on the columns they
+        share (QueryProcessor.executeFinalQuery with a query map of several statements)."""
+        arr = (c_char_p * len(statements))(*[q.encode("utf-8", "surrogateescape") for q in statements])
+        h = c_void_p(None)
+        self._check(self.lib.dx_query_joined(self.ctx, arr, len(statements), mode, byref(h)))
+        r = QueryResult(self, h)
+        self._results.add(r)
+        return r
 
     def query(self, sql: str, mode: int = DX_QUERY_COUNT) -> QueryResult:
         h = c_void_p(None)

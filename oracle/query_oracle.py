@@ -78,15 +78,41 @@ class SqliteProcessor:
 
     def execute(self, query_map: dict):
         """Returns (columns, rows) -- rows as a list of tuples of raw terms."""
-        if len(query_map) != 1:
-            raise NotImplementedError("multi-statement files are never produced by the translator")
-        sql = _strip_union_parens(next(iter(query_map.values())))
         if not getattr(self, "analysed", True):
             self.db.execute("ANALYZE")
             self.analysed = True
-        cur = self.db.execute(sql)
-        cols = [d[0] for d in cur.description]
-        return cols, cur.fetchall()
+        if len(query_map) == 1:
+            cur = self.db.execute(_strip_union_parens(next(iter(query_map.values()))))
+            cols = [d[0] for d in cur.description]
+            return cols, cur.fetchall()
+        # QueryProcessor.executeFinalQuery (QueryProcessor.scala:184-195) with several statements: each is executed, and the
+        # results are folded left to right with customJoin (:197-208): an inner join on the columns both sides have
+        # (commonColumns, :276-278), or a cross join when they have none. Done here on materialised results, the way
+        # it reads; bags throughout (neither side is made distinct).
+        acc_cols, acc_rows = None, None
+        for sql in query_map.values():
+            cur = self.db.execute(_strip_union_parens(sql))
+            cols = [d[0] for d in cur.description]
+            rows = cur.fetchall()
+            if acc_cols is None:
+                acc_cols, acc_rows = cols, rows
+                continue
+            common = [c for c in acc_cols if c in cols]
+            li = [acc_cols.index(c) for c in common]
+            ri = [cols.index(c) for c in common]
+            l_rest = [i for i, c in enumerate(acc_cols) if c not in common]
+            r_rest = [i for i, c in enumerate(cols) if c not in common]
+            by_key = {}
+            for r in rows:
+                by_key.setdefault(tuple(r[i] for i in ri), []).append(r)
+            out = []
+            for l in acc_rows:
+                key = tuple(l[i] for i in li)
+                for r in by_key.get(key, ()):
+                    out.append(tuple(key) + tuple(l[i] for i in l_rest) + tuple(r[i] for i in r_rest))
+            acc_cols = common + [acc_cols[i] for i in l_rest] + [cols[i] for i in r_rest]
+            acc_rows = out
+        return acc_cols, acc_rows
 
 
 def run_query(vp: dict, translated_text: str):

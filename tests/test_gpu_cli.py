@@ -101,6 +101,19 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
             continue
         r = query_oracle.run_query(ref["vp"], tr)
         want[name] = (r["count"], r["load_data"], r["tp"])
+    # a file with several statements (QueryProcessor.scala:73-88, 184-208): Q9's three edge patterns as three statements whose
+    # results share Y, then X and Z -- never written by the translator, made by hand here
+    _, q9_parts, _ = query_oracle.parse_translated_file((qdir / "Q9.txt").read_text())
+    edge = {k: next(p_ for p_ in q9_parts if k in p_.lower()) for k in ("advisor", "teacherof", "takescourse")}
+    tbl = {k: query_oracle.clean_table_name(v) for k, v in edge.items()}
+    multi = (">>>>> Q9 as three statements\npartitions %s\nTP 3\n" % ",".join(edge.values()) +
+             "a SELECT tab0.X AS X,tab0.Y AS Y FROM (SELECT s AS X, o AS Y FROM %s) AS tab0 \n" % tbl["advisor"] +
+             "b SELECT tab0.Y AS Y,tab0.Z AS Z FROM (SELECT s AS Y, o AS Z FROM %s) AS tab0 \n" % tbl["teacherof"] +
+             "c SELECT tab0.X AS X,tab0.Z AS Z FROM (SELECT s AS X, o AS Z FROM %s) AS tab0 " % tbl["takescourse"])
+    (qdir / "Q90_three_statements.txt").write_text(multi)
+    r = query_oracle.run_query(ref["vp"], multi)
+    assert r["count"] > 0
+    want["Q90_three_statements.txt"] = (r["count"], r["load_data"], r["tp"])
 
     p = subprocess.run([os.path.join(BIN, "dx-query"), "LUBM", "4", base, str(qdir)], cwd=cwd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
@@ -122,7 +135,7 @@ def test_dap_then_query_round_trip(lubm1, tmp_path):
     import csv
     p = subprocess.run([os.path.join(BIN, "dx-query-cold"), "4"], cwd=cwd, capture_output=True, text=True)
     assert p.returncode == 255 and p.stdout.startswith("Arguments: number of partitions, query file")
-    for name in ("Q4.txt", "Q9.txt", "Q14.txt"):
+    for name in ("Q4.txt", "Q9.txt", "Q14.txt", "Q90_three_statements.txt"):
         tr = (qdir / name).read_text()
         qm, partitions, tp = query_oracle.parse_translated_file(tr)
         proc = query_oracle.SqliteProcessor(ref["vp"])

@@ -129,6 +129,60 @@ def test_striped_intermediates_at_a_size_that_stripes_by_itself(monkeypatch):
         e.close()
 
 
+def test_several_statements_in_one_file_are_joined_like_customJoin(loaded, lubm1):
+    """A translated file may hold several statements (QueryProcessor.scala:73-88); executeFinalQuery runs each and folds the
+    results with customJoin (:184-208): inner join on the output columns two results share, cross join when they share
+    none. The translator never writes such a file, so these are made by hand over LUBM-1's tables: Q9's triangle as three
+    one-pattern statements (joined on Y, then on X and Z), the same in another order, two statements without a common
+    column, and one statement alone through the same entry point. The oracle executes every statement in SQLite and
+    joins the materialised results the way the reference's code reads."""
+    import re
+    from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
+    from oracle.query_oracle import SqliteProcessor, clean_table_name, parse_translated_file
+    e, translated = loaded
+    qm, parts, _ = parse_translated_file(translated["Q9.txt"])
+    by_pred = {}
+    for p in parts:
+        for k in ("advisor", "teacherof", "takescourse"):
+            if k in p.lower():
+                by_pred[k] = p
+    assert len(by_pred) == 3
+    t = {k: clean_table_name(p) for k, p in by_pred.items()}
+    one = {
+        "adv": "SELECT tab0.X AS X,tab0.Y AS Y FROM (SELECT s AS X, o AS Y FROM %s) AS tab0 " % t["advisor"],
+        "tea": "SELECT tab0.Y AS Y,tab0.Z AS Z FROM (SELECT s AS Y, o AS Z FROM %s) AS tab0 " % t["teacherof"],
+        "tak": "SELECT tab0.X AS X,tab0.Z AS Z FROM (SELECT s AS X, o AS Z FROM %s) AS tab0 " % t["takescourse"],
+    }
+    course = lubm1["oracle"]["vp"][tuple(by_pred["teacherof"].split("-", 1))][0][1]
+    few = "SELECT tab0.W AS W FROM (SELECT s AS W FROM %s WHERE o == '%s') AS tab0 " % (t["teacherof"], course)
+    cases = [["adv", "tea", "tak"], ["tak", "adv", "tea"], ["tea", "tak"], ["adv"]]
+    files = [[(n, one[n]) for n in c] for c in cases] + [[("few", few), ("tea", one["tea"])], [("tea", one["tea"]), ("few", few), ("adv", one["adv"])]]
+    proc = SqliteProcessor(lubm1["oracle"]["vp"])
+    proc.preload(list(by_pred.values()))
+    e.unload_all()
+    for p in by_pred.values():
+        e.load_table(p)
+    seen_rows = 0
+    for stmts in files:
+        text = ">>>>> made by hand\npartitions %s\nTP %d\n%s" % (",".join(by_pred.values()), len(stmts), "\n".join("%s %s" % s for s in stmts))
+        query_map, _, _ = parse_translated_file(text)
+        assert list(query_map.values()) == [q for _, q in stmts]
+        cols, rows = proc.execute(query_map)
+        r = e.query_joined([q for _, q in stmts], DX_QUERY_COUNT)
+        assert r.count == len(rows), [n for n, _ in stmts]
+        rb = e.query_joined([q for _, q in stmts], DX_QUERY_BINDINGS)
+        assert rb.columns == cols, [n for n, _ in stmts]      # Spark's order: shared columns, the left side's, the right side's
+        got, got_cols = rb.rows()
+        order = sorted(range(len(cols)), key=lambda i: cols[i])
+        assert got_cols == [cols[i] for i in order]
+        assert got == sorted(tuple(row[i] for i in order) for row in rows), [n for n, _ in stmts]
+        seen_rows += len(rows)
+    assert seen_rows > 1000
+    # the triangle as three statements is Q9 without its type patterns: at least as many rows as Q9 itself
+    from oracle.query_oracle import run_query
+    assert e.query_joined([one["adv"], one["tea"], one["tak"]]).count >= run_query(lubm1["oracle"]["vp"], translated["Q9.txt"])["count"] > 0
+
+
 def test_remembered_parse_and_join_order_change_nothing(loaded, lubm1, monkeypatch):
     """A statement that comes again skips the parser and the join-order search (its text and the statistics the
     search looked at are the key): same plan, same count as with DX_NO_PLAN_CACHE=1, which always parses and searches."""
@@ -252,6 +306,52 @@ def test_union_and_constant_projection(loaded, lubm1):
     assert gcols == [cols[i] for i in order]
     assert got == sorted(tuple(r[i] for i in order) for r in rows)
     assert res.count == len(rows) > 0
+
+
+def test_union_is_a_set_also_across_different_arms(loaded, lubm1):
+    """SQL's UNION (what QueryTranslator.scala:485-491, 507-526 write between the arms) returns every row once. The
+    translator's own arms each project their own constant and both columns, so their rows never coincide; arms written
+    by hand can: one column of two tables, the same constant in two arms, an arm that drops a column of its table, an
+    arm with a filter beside one without. Counts and bindings against SQLite, alone and joined with another pattern."""
+    from opus_amd.engine import DX_QUERY_BINDINGS
+    from oracle.query_oracle import SqliteProcessor, clean_table_name
+    e, translated = loaded
+    O = "http://www.lehigh.edu/~zhp2/2004/0401/univ-bench.owl#"
+    pre = "00002-_3=_http___www_lehigh_edu__zhp2_2004_0401_univ_bench_owl_"
+    parts = [pre + "memberof_", pre + "takescourse_", pre + "advisor_", "00002-_3=_http___www_w3_org_1999_02_22_rdf_syntax_ns_type_"]
+    mem, tak, adv, typ = (clean_table_name(p) for p in parts)
+    dept = "<http://www.Department0.University0.edu>"
+    unions = {
+        "subjects of two tables": "( (SELECT s AS X FROM %s)UNION(SELECT s AS X FROM %s) )" % (mem, tak),
+        "both columns, one arm turned round": "( (SELECT s AS X, o AS Y FROM %s)UNION(SELECT o AS X, s AS Y FROM %s)UNION(SELECT s AS X, o AS Y FROM %s) )" % (adv, adv, mem),
+        "same constant twice, another once": "( (SELECT s AS X, '<p1>' AS P FROM %s)UNION(SELECT s AS X, '<p1>' AS P FROM %s)UNION(SELECT s AS X, '<p2>' AS P FROM %s) )" % (mem, tak, adv),
+        "a filtered arm beside a plain one": "( (SELECT s AS X FROM %s WHERE o == '%s')UNION(SELECT s AS X FROM %s) )" % (mem, dept, adv),
+        "one arm that drops a column": "( (SELECT o AS Y FROM %s)UNION(SELECT o AS Y FROM %s WHERE s == '<no such term>') )" % (tak, mem),
+    }
+    proc = SqliteProcessor(lubm1["oracle"]["vp"])
+    proc.preload(parts)
+    e.unload_all()
+    for p in parts:
+        e.load_table(p)
+    shrunk = 0
+    for what, u in unions.items():
+        names = [c.split(" AS ")[1].strip() for c in u.split("FROM")[0].split("SELECT")[1].split(",")]
+        alone = "SELECT %s FROM %s AS tab0 " % (",".join("tab0.%s AS %s" % (n, n) for n in names), u)
+        joined = ("SELECT %s FROM %s AS tab0, (SELECT s AS %s FROM %s WHERE o == '<%sGraduateStudent>') AS tab1 WHERE tab0.%s=tab1.%s " %
+                  (",".join("tab0.%s AS %s" % (n, n) for n in names), u, names[0], typ, O, names[0], names[0]))
+        for sql in (alone, joined):
+            cols, rows = proc.execute({"X": sql})
+            for _ in range(2):                      # the second time the duplicate-free table of the arms is already there
+                res = e.query(sql, DX_QUERY_BINDINGS)
+                got, gcols = res.rows()
+                order = sorted(range(len(cols)), key=lambda i: cols[i])
+                assert gcols == [cols[i] for i in order], what
+                assert got == sorted(tuple(r[i] for i in order) for r in rows), what
+                assert res.count == e.query(sql).count == len(rows), what
+        bag = sum(len(proc.execute({"X": "SELECT tab0.%s AS %s FROM %s AS tab0 " % (names[0], names[0], arm.strip().rstrip(")").rstrip() + ")")})[1])
+                  for arm in u.strip()[1:-1].split("UNION"))
+        shrunk += bag > len(proc.execute({"X": alone})[1])
+    assert shrunk >= 4   # in nearly every case the arms' rows do coincide: concatenating them would count too many
 
 
 def test_unknown_constant_and_empty_result(loaded):
