@@ -336,6 +336,70 @@ __device__ __forceinline__ bool arm_row(const ArmDev& a, const int64_t* __restri
   return true;
 }
 
+// The rows a thread takes from one tile (rows first, first + 256, ...), fetched side by side: the filtered columns of
+// all of them first (without a filter: everything the tuple needs), then the other column of the rows that passed.
+// Taken row after row, every row waits for its own round trips to memory one after the other, and a kernel
+// that is a chain of such waits runs at the memory's latency, not its rate. Returns the rows that pass as a bit
+// mask; v[j] is set for those. pre_s / pre_o: values of the filtered columns requested earlier (when `pre`).
+template <int kR>
+__device__ __forceinline__ uint32_t arm_rows(const ArmDev& a, int64_t want_s, int64_t want_o, uint32_t first, int64_t (&v)[kR][3],
+                                            bool pre = false, const int64_t* pre_s = nullptr, const int64_t* pre_o = nullptr) {
+  uint32_t pass = 0;
+  if (a.direct) {
+#pragma unroll
+    for (int j = 0; j < kR; ++j) {
+      const uint32_t i = first + j * 256;
+      if (i < a.rows) {
+        pass |= 1u << j;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < a.nsrc) v[j][k] = a.d[k][i];
+      }
+    }
+    return pass;
+  }
+  bool need_s = false, need_o = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < a.nsrc) { need_s |= a.src[k] == 0; need_o |= a.src[k] == 1; }
+  const bool filtered = a.fs >= 0 || a.fo >= 0;
+  int64_t s[kR], o[kR];
+#pragma unroll
+  for (int j = 0; j < kR; ++j) {
+    const uint32_t i = first + j * 256;
+    s[j] = o[j] = 0;
+    if (i < a.rows) {
+      if (a.fs >= 0) s[j] = pre ? pre_s[j] : a.s[i];
+      else if (need_s && !filtered) s[j] = a.s[i];
+      if (a.fo >= 0) o[j] = pre ? pre_o[j] : a.o[i];
+      else if (need_o && !filtered) o[j] = a.o[i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kR; ++j) {
+    const uint32_t i = first + j * 256;
+    if (i < a.rows && (a.fs < 0 || s[j] == want_s) && (a.fo < 0 || o[j] == want_o)) pass |= 1u << j;
+  }
+  if (filtered) {
+#pragma unroll
+    for (int j = 0; j < kR; ++j) {
+      const uint32_t i = first + j * 256;
+      if (pass >> j & 1) {
+        if (need_s && a.fs < 0) s[j] = a.s[i];
+        if (need_o && a.fo < 0) o[j] = a.o[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kR; ++j)
+    if (pass >> j & 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < a.nsrc) v[j][k] = a.src[k] == 0 ? s[j] : a.src[k] == 1 ? o[j] : a.src_val[k];
+    }
+  return pass;
+}
+
 // Filtered scan that only counts (single-relation count queries). The grid is kept to kCountBlocks blocks: the
 // kernel ends with one atomic per block on one word, and the L2 carries those out one after another (two
 // thousand of them took longer than reading the column). A thread therefore walks many rows, and in the
@@ -548,11 +612,22 @@ __global__ void __launch_bounds__(256) k_probe(ProbeArgs p, Epilogue ep) {
     int64_t v[kRowsPerThread][3];
     uint32_t head[kRowsPerThread];
     uint32_t n = 0;
+    // With the table in LDS the kernel is a stream over the arm: its rows are fetched side by side. With the table in
+    // HBM the probes are what takes the time, and more waves per SIMD (fewer registers) serve them better.
+    uint32_t pass = 0;
+    if constexpr (kLds) {
+      pass = arm_rows<kRowsPerThread>(p.arm, want_s, want_o, tile * kTileRows + threadIdx.x, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kRowsPerThread; ++j) {
+        const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
+        if (i < p.arm.rows && arm_row(p.arm, p.consts, want_s, want_o, i, v[j])) pass |= 1u << j;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kRowsPerThread; ++j) {
-      const uint32_t i = tile * kTileRows + j * 256 + threadIdx.x;
       head[j] = kNil;
-      if (i < p.arm.rows && arm_row(p.arm, p.consts, want_s, want_o, i, v[j])) {
+      if (pass >> j & 1) {
         if (p.nkey == 0) {
           head[j] = nI ? 0u : kNil;
         } else {
@@ -1248,6 +1323,21 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
       auto it = ctx->q_regular_steps.find(sql_key);
       if (it != ctx->q_regular_steps.end()) regular_steps = it->second;
     }
+    // Rows after each step: the planner's estimates, or -- when this statement has run over these tables before --
+    // what the steps really produced then. Only sizes and the choice between equivalent ways to run a step depend on
+    // them, never a result: a wrong one costs a second attempt (a table that does not fit LDS, a buffer too small).
+    std::vector<double> rows_hint = plan.est_rows;
+    bool rows_seen = false;
+    uint64_t tables_signature = 0x9E3779B97F4A7C15ull * (uint64_t)nsteps;
+    for (const auto& r : plan.rels)
+      for (const auto& a : r.arms) tables_signature = mix64(tables_signature ^ (uint64_t)a.t->rows ^ (uint64_t)(uintptr_t)a.t->s);
+    if (plan_cache_enabled() && !getenv("DX_NO_ROW_FEEDBACK")) {
+      auto it = ctx->q_seen_rows.find(sql_key);
+      if (it != ctx->q_seen_rows.end() && it->second.signature == tables_signature && (int)it->second.rows.size() == nsteps) {
+        rows_hint.assign(it->second.rows.begin(), it->second.rows.end());
+        rows_seen = true;
+      }
+    }
     const bool fused = ca.n <= kProConsts && off <= (uint32_t)kProBytes && ctx->q_counters && !getenv("DX_QUERY_UNFUSED");
     for (int attempt = 0; attempt <= 2 * nsteps + 2; ++attempt) {
       const auto t_attempt = std::chrono::steady_clock::now();
@@ -1282,15 +1372,16 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           for (int c = 0; c < r.ncols; ++c)
             if (std::find(cls.begin(), cls.end(), r.cls[c]) != cls.end()) ++step_nkey[k];
             else cls.push_back(r.cls[c]);
-          step_small[k] = fused && step_nkey[k] > 0 && !(regular_steps & (1ull << k)) && k - 1 < (int)plan.est_rows.size() &&
-                          plan.est_rows[k - 1] <= kLdsRows / 4 && !no_lds_tables;
+          // an estimate is trusted up to a quarter of the table's room, a count seen before up to all of it
+          step_small[k] = fused && step_nkey[k] > 0 && !(regular_steps & (1ull << k)) && k - 1 < (int)rows_hint.size() &&
+                          rows_hint[k - 1] <= (rows_seen ? kLdsRows : kLdsRows / 4) && !no_lds_tables;
         }
       }
       uint32_t striped = 0;
       unsigned long long* const stripes_p = counters_p + kStripeCountersAt;
       auto stripe_output = [&](int k) {
-        return fused && k + 1 < nsteps && k < (int)plan.est_rows.size() && step_nkey[k + 1] > 0 && !step_small[k + 1] &&
-               join_stripe_rows() > 0 && plan.est_rows[k] >= (double)join_stripe_rows();
+        return fused && k + 1 < nsteps && k < (int)rows_hint.size() && step_nkey[k + 1] > 0 && !step_small[k + 1] &&
+               join_stripe_rows() > 0 && rows_hint[k] >= (double)join_stripe_rows();
       };
       // the stripes do not end level: room for the fullest one's lead over the average
       auto striped_cap = [](uint64_t cap) { return cap + cap / 8 + ((uint64_t)kStripes << kStripeGroupBits) * 2; };
@@ -1380,7 +1471,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           if (a.t->rows) { ++arms_here; only_arm = &a; }
         bool reverse = false;
         if (pa.nkey > 0 && !small && arms_here == 1 && join_reverse_mode() != 0) {
-          const double i_est = k - 1 < (int)plan.est_rows.size() ? plan.est_rows[k - 1] : (double)I.cap;
+          const double i_est = k - 1 < (int)rows_hint.size() ? rows_hint[k - 1] : (double)I.cap;
           reverse = join_reverse_mode() > 0 || 2.0 * std::min<double>(r.est, (double)only_arm->t->rows) <= i_est;
         }
         if (reverse) {
@@ -1398,8 +1489,9 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           // rows that could arrive: the heads of all steps are filled before the first scan and read at random by the
           // probes, so a table sized for the buffer's capacity costs time in both when the filters are selective.
           uint64_t expect = I.cap;
-          if (k - 1 < (int)plan.est_rows.size())
-            expect = std::min<uint64_t>(I.cap, std::max<uint64_t>((uint64_t)std::min(4.0 * plan.est_rows[k - 1], 4.0e9), I.cap / 16));
+          if (k - 1 < (int)rows_hint.size())
+            expect = rows_seen ? std::min<uint64_t>(I.cap, (uint64_t)std::min(rows_hint[k - 1] + 1.0, 4.0e9))
+                               : std::min<uint64_t>(I.cap, std::max<uint64_t>((uint64_t)std::min(4.0 * rows_hint[k - 1], 4.0e9), I.cap / 16));
           uint32_t hsize = 1024;
           while (hsize < 2ull * expect && hsize < (1u << 31)) hsize <<= 1;
           my_heads_off = heads_words;
@@ -1426,7 +1518,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         if (!count_only) {
           // optimistic capacity: what flows in, or twice the estimate if that is more; a miss costs one re-run
           const uint64_t guess = std::max<uint64_t>(std::max<uint64_t>(I.cap, r.rows_upper),
-                                                    (uint64_t)std::min(2.0 * plan.est_rows[k], 4.0e8));
+                                                    (uint64_t)std::min(2.0 * rows_hint[k], 4.0e8));
           uint64_t cap = std::max<uint64_t>(caps[k] ? caps[k] : guess, 1);
           if (stripe_output(k) && striped_cap(cap) < (1ull << 32)) {
             if (!caps[k]) cap = striped_cap(cap);
@@ -1581,6 +1673,12 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         res->host_us[0] = us(t_attempt, t_laid_out);
         res->host_us[1] = us(t_laid_out, t_queued);
         res->host_us[2] = us(t_queued, t_done);
+      }
+      if (plan_cache_enabled()) {
+        if (ctx->q_seen_rows.size() > 4096) ctx->q_seen_rows.clear();
+        dx_ctx::SeenRows& seen = ctx->q_seen_rows[sql_key];
+        seen.signature = tables_signature;
+        seen.rows.assign(hb->counters, hb->counters + nsteps);
       }
       res->plan_steps.resize(nsteps);
       for (int k = 0; k < nsteps; ++k) {

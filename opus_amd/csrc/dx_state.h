@@ -176,6 +176,8 @@ struct dx_ctx {
   // group's description; emptied whenever the catalogue is
   std::unordered_map<std::string, std::unique_ptr<dx::CatalogTable>> union_tables;
   std::unordered_map<size_t, uint64_t> q_regular_steps;  // per statement text: join steps that need their hash table in HBM
+  struct SeenRows { uint64_t signature = 0; std::vector<uint64_t> rows; };
+  std::unordered_map<size_t, SeenRows> q_seen_rows;       // per statement text: rows after each step the last time it ran (over the tables `signature` stands for)
   // Statements come again: the parsed form is kept per text, and the join order the search found per (text, numbers the
   // search looked at), so a repeated statement over tables with the same statistics skips both (DX_NO_PLAN_CACHE=1: never).
   std::unordered_map<std::string, std::shared_ptr<const dx::SqlQuery>> q_parsed;

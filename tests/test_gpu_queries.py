@@ -202,6 +202,28 @@ def test_remembered_parse_and_join_order_change_nothing(loaded, lubm1, monkeypat
         assert len(plan_lines(fresh)) >= 3
 
 
+@pytest.mark.parametrize("name", ["Q%d.txt" % i for i in (2, 4, 7, 8, 9, 12)])
+def test_rows_seen_on_an_earlier_run_change_nothing(loaded, lubm1, monkeypatch, name):
+    """A statement that has run before sizes its steps (LDS or HBM table, heads, stripes, buffers) by the rows each
+    step produced then instead of the planner's estimates: same count, same bindings, with the feedback off
+    (DX_NO_ROW_FEEDBACK=1), on the run that records the rows and on the runs that use them."""
+    from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
+    from oracle.query_oracle import run_query
+    e, translated = loaded
+    ref = run_query(lubm1["oracle"]["vp"], translated[name])
+    monkeypatch.setenv("DX_NO_ROW_FEEDBACK", "1")
+    off, _ = _run_file(e, translated[name], DX_QUERY_BINDINGS)
+    monkeypatch.delenv("DX_NO_ROW_FEEDBACK")
+    assert off.count == ref["count"]
+    assert off.rows()[0] == ref["rows"]
+    for _ in range(3):
+        c, _ = _run_file(e, translated[name], DX_QUERY_COUNT)
+        assert c.count == ref["count"], name
+        b, _ = _run_file(e, translated[name], DX_QUERY_BINDINGS)
+        assert b.count == ref["count"]
+        assert b.rows()[0] == ref["rows"], name
+
+
 @pytest.fixture(scope="module")
 def loaded_swat(lubm1_swat):
     """The same for the second namespace the reference ships queries for (queries/lubm10240)."""
