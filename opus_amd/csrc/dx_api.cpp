@@ -1197,6 +1197,7 @@ static CatalogTable& register_table(dx_ctx* ctx, const char* partition_key) {
       } else {
         it->second.distinct_s = st->second.first;
         it->second.distinct_o = st->second.second;
+        it->second.sorted_s = st->second.sorted_s && it->second.slices.size() == 1;
       }
     }
     return it->second;

@@ -2041,14 +2041,17 @@ static std::string uri_to_storage(const std::string& s) {  // DAP.scala:512-514:
 // of caching the table, QueryProcessor.scala:222-232). Subjects are counted on the stored order when the
 // table is one sorted slice; any other column is counted through a byte per term.
 __global__ void __launch_bounds__(256)
-k_count_changes(const uint64_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ out) {
+k_count_changes(const uint64_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ out, unsigned long long* __restrict__ descents) {
   __shared__ uint32_t lds[8];
-  uint32_t c = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+  uint32_t c = 0, down = 0;  // down: places where the order the count relies on does not hold
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     c += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+    down += (i != 0 && v[i] < v[i - 1]) ? 1u : 0u;
+  }
   uint32_t total;
   (void)block_excl_scan_256<uint32_t>(c, lds, total);
   if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
+  if (__syncthreads_or(down != 0) && threadIdx.x == 0) atomicAdd(descents, 1ull);
 }
 
 // Distinct values of a column without sorting it: one byte per term, set by plain stores (every writer stores
@@ -2079,7 +2082,8 @@ k_count_marked(const uint8_t* __restrict__ seen, uint64_t n_padded /*multiple of
 // pass over a byte per dictionary term for each of them was milliseconds per statement.
 constexpr uint32_t kSmallStatsRows = 16384, kSmallStatsSlots = 32768;
 struct SmallTable { const int64_t* s; const int64_t* o; uint32_t rows, sorted_s; };
-__global__ void __launch_bounds__(256) k_stats_small(const SmallTable* __restrict__ tabs, const uint32_t* __restrict__ where, unsigned long long* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_stats_small(const SmallTable* __restrict__ tabs, const uint32_t* __restrict__ where, unsigned long long* __restrict__ out,
+                                                      unsigned long long* __restrict__ descents) {
   __shared__ uint32_t set[kSmallStatsSlots];
   __shared__ uint32_t lds[8];
   const SmallTable t = tabs[blockIdx.x];
@@ -2087,7 +2091,12 @@ __global__ void __launch_bounds__(256) k_stats_small(const SmallTable* __restric
     const int64_t* __restrict__ v = col ? t.o : t.s;
     uint32_t c = 0;
     if (col == 0 && t.sorted_s) {
-      for (uint32_t i = threadIdx.x; i < t.rows; i += 256) c += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+      uint32_t down = 0;
+      for (uint32_t i = threadIdx.x; i < t.rows; i += 256) {
+        c += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+        down += (i != 0 && (uint64_t)v[i] < (uint64_t)v[i - 1]) ? 1u : 0u;
+      }
+      if (__syncthreads_or(down != 0) && threadIdx.x == 0) descents[where[blockIdx.x]] = 1;
     } else {
       for (uint32_t i = threadIdx.x; i < kSmallStatsSlots; i += 256) set[i] = 0xFFFFFFFFu;
       __syncthreads();
@@ -2119,14 +2128,14 @@ void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
   if (todo.empty()) return;
   if (!ctx->dict.valid()) throw DxError(DX_E_INVAL, "no dictionary loaded");
   const uint64_t n_terms = ctx->dict.n_terms;
-  DevBuf<unsigned long long> cnt(ctx->pool, 2 * todo.size());
-  DX_HIP(hipMemsetAsync(cnt.p, 0, 16 * todo.size(), s));
+  DevBuf<unsigned long long> cnt(ctx->pool, 3 * todo.size());  // distinct s, distinct o per table, then a word per table for the order of s
+  DX_HIP(hipMemsetAsync(cnt.p, 0, 24 * todo.size(), s));
   std::vector<SmallTable> small;
   std::vector<uint32_t> small_where;
   for (size_t k = 0; k < todo.size(); ++k) {
     const CatalogTable& t = *todo[k];
     if (t.rows == 0 || t.rows > kSmallStatsRows) continue;
-    small.push_back({t.s, t.o, (uint32_t)t.rows, t.slices.size() == 1 ? 1u : 0u});
+    small.push_back({t.s, t.o, (uint32_t)t.rows, t.slices.size() == 1 && !t.unsorted_s ? 1u : 0u});
     small_where.push_back((uint32_t)k);
   }
   DevBuf<SmallTable> d_small(ctx->pool, small.size());
@@ -2134,7 +2143,7 @@ void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
   if (!small.empty()) {
     DX_HIP(hipMemcpyAsync(d_small.p, small.data(), small.size() * sizeof(SmallTable), hipMemcpyHostToDevice, s));
     DX_HIP(hipMemcpyAsync(d_where.p, small_where.data(), small.size() * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_stats_small, dim3((unsigned)small.size()), dim3(256), 0, s, d_small.p, d_where.p, cnt.p);
+    hipLaunchKernelGGL(k_stats_small, dim3((unsigned)small.size()), dim3(256), 0, s, d_small.p, d_where.p, cnt.p, cnt.p + 2 * todo.size());
   }
   const uint64_t n_padded = (n_terms + 15) / 16 * 16 + 16;
   DevBuf<uint8_t> seen;  // one map for all large tables: the stream runs them one after another
@@ -2144,11 +2153,11 @@ void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
     if (!seen.p) seen = DevBuf<uint8_t>(ctx->pool, n_padded);
     // grids of a few hundred blocks: every block ends with one atomic on the same counter
     const unsigned g = (unsigned)std::min<uint64_t>(256, (t.rows + 255) / 256);
-    const bool sorted_s = t.slices.size() == 1;  // one slice of a partition: rows are in (s, o) order
+    const bool sorted_s = t.slices.size() == 1 && !t.unsorted_s;  // one slice of a partition: rows are in (s, o) order (looked at while counting)
     for (int col = 0; col < 2; ++col) {
       const int64_t* src = col == 0 ? t.s : t.o;
       if (col == 0 && sorted_s) {
-        hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, (const uint64_t*)src, t.rows, cnt.p + 2 * k + col);
+        hipLaunchKernelGGL(k_count_changes, dim3(g), dim3(256), 0, s, (const uint64_t*)src, t.rows, cnt.p + 2 * k + col, cnt.p + 2 * todo.size() + k);
         continue;
       }
       DX_HIP(hipMemsetAsync(seen.p, 0, n_padded, s));
@@ -2157,16 +2166,27 @@ void table_statistics(dx_ctx* ctx, const std::vector<CatalogTable*>& tables) {
                          cnt.p + 2 * k + col);
     }
   }
-  std::vector<unsigned long long> h(2 * todo.size(), 0);
-  DX_HIP(hipMemcpyAsync(h.data(), cnt.p, 16 * todo.size(), hipMemcpyDeviceToHost, s));
+  std::vector<CatalogTable*> recount;
+  std::vector<unsigned long long> h(3 * todo.size(), 0);
+  DX_HIP(hipMemcpyAsync(h.data(), cnt.p, 24 * todo.size(), hipMemcpyDeviceToHost, s));
   DX_HIP(hipStreamSynchronize(s));
   for (size_t k = 0; k < todo.size(); ++k) {
     CatalogTable& t = *todo[k];
     t.distinct_s = h[2 * k];
     t.distinct_o = h[2 * k + 1];
+    // a table that is one slice had its subjects' order looked at while they were counted
+    t.sorted_s = t.rows > 0 && t.slices.size() == 1 && !t.unsorted_s && h[2 * todo.size() + k] == 0;
     t.stats_pending = false;
-    if (!t.key.empty()) ctx->table_stats[t.key] = {t.distinct_s, t.distinct_o};  // survive unloadTables: the data does not change
+    if (t.slices.size() == 1 && !t.unsorted_s && h[2 * todo.size() + k] != 0) {
+      // a table from somebody else's files, in no particular order: its subjects' changes were no count of them
+      t.unsorted_s = true;
+      t.stats_pending = true;
+      recount.push_back(&t);
+      continue;
+    }
+    if (!t.key.empty()) ctx->table_stats[t.key] = {t.distinct_s, t.distinct_o, t.sorted_s};  // survive unloadTables: the data does not change
   }
+  if (!recount.empty()) table_statistics(ctx, recount);
 }
 
 namespace {

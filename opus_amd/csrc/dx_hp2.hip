@@ -796,6 +796,77 @@ __global__ void __launch_bounds__(256) k_probe_rev(ProbeArgs p, Epilogue ep) {
   stmt_epilogue(ep);
 }
 
+// ---- the same join without a table: the arm is stored in ascending order of its subjects, one of the join's key
+// columns is that subject, and the intermediate is small beside the arm. Every row of the intermediate finds the
+// first row of its subject in the arm by bisection (the upper levels stay in cache) and walks the rows of that
+// subject: some twenty dependent reads per row instead of a pass over the whole arm. s_key: which of the key columns
+// is the arm's subject. The arm has no constant on its subject. Output rows as k_probe's.
+__global__ void __launch_bounds__(256) k_probe_sorted(ProbeArgs p, int s_key, Epilogue ep) {
+  const uint32_t nI = rel_rows(p.I);
+  const int64_t want_s = 0, want_o = p.arm.fo >= 0 ? p.consts[p.arm.fo] : 0;
+  const int64_t* __restrict__ as = p.arm.s;
+  const uint32_t rows = p.arm.rows;
+  auto matches = [&](const int64_t (&v)[3], int64_t k0, int64_t k1) {
+    return pick3(v, p.key_src[0]) == k0 && (p.nkey < 2 || pick3(v, p.key_src[1]) == k1);
+  };
+  const uint32_t ntiles = (nI + 255) / 256;
+  unsigned long long local = 0;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // block-uniform
+    const uint32_t r = tile * 256 + threadIdx.x;
+    int64_t k0 = 0, k1 = 0;
+    uint32_t lo = rows, n = 0;
+    if (r < nI && row_is_there(p.I, r)) {
+      k0 = p.I.col[p.key_col[0]][r];
+      if (p.nkey == 2) k1 = p.I.col[p.key_col[1]][r];
+      const int64_t ks = s_key == 0 ? k0 : k1;
+      uint32_t a = 0, b = rows;
+      while (a < b) {
+        const uint32_t m = a + (b - a) / 2;
+        if (as[m] < ks) a = m + 1; else b = m;
+      }
+      lo = a;
+      for (uint32_t i = lo; i < rows && as[i] == ks; ++i) {
+        if (p.arm.fo >= 0 && p.arm.o[i] != want_o) continue;
+        int64_t v[3];
+        arm_tuple(p.arm, want_s, want_o, i, v);
+        if (matches(v, k0, k1)) ++n;
+      }
+    }
+    if (p.count_only) { local += n; continue; }
+    uint32_t before;
+    unsigned long long idx = block_claim(n, claim_counter(p.out, p.out_count), before) + before;
+    if (!n) continue;
+    const int64_t ks = s_key == 0 ? k0 : k1;
+    for (uint32_t i = lo; i < rows && as[i] == ks; ++i) {
+      if (p.arm.fo >= 0 && p.arm.o[i] != want_o) continue;
+      int64_t v[3];
+      arm_tuple(p.arm, want_s, want_o, i, v);
+      if (!matches(v, k0, k1)) continue;
+      const uint64_t pos = out_row(p.out, idx);
+      if (pos < p.out.cap) {
+        for (int c = 0; c < p.I.ncols; ++c) p.out.col[c][pos] = p.I.col[c][r];
+        for (int c = 0; c < p.nnew; ++c) p.out.col[p.I.ncols + c][pos] = pick3(v, p.new_src[c]);
+      }
+      ++idx;
+    }
+  }
+  if (p.count_only) {  // one atomic per block
+    __shared__ uint64_t lds64[8];
+    uint64_t block_total;
+    (void)block_excl_scan_256<uint64_t>(local, lds64, block_total);
+    stmt_epilogue(ep, block_total, p.out_count);
+    return;
+  }
+  stmt_epilogue(ep);
+}
+
+// DX_JOIN_LOOKUP: 0 = never, 1 = whenever the arm allows it; otherwise when the arm has at least 2^20 rows and twice as
+// many as the intermediate is expected to hold
+static int join_lookup_mode() {
+  const char* e = getenv("DX_JOIN_LOOKUP");  // (read per statement: the tests switch it)
+  return !e ? -1 : atoi(e);
+}
+
 // DX_JOIN_REVERSE: 0 = the table is always built over the intermediate, 1 = over the arm whenever that is possible;
 // otherwise over the arm when it is expected to hold at most half as many rows as the intermediate
 static int join_reverse_mode() {
@@ -1469,8 +1540,20 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
         const PlanRel::Arm* only_arm = nullptr;
         for (const auto& a : r.arms)
           if (a.t->rows) { ++arms_here; only_arm = &a; }
+        // the arm's subject among the join's keys, the arm in ascending order of it, and few rows to look up beside the
+        // arm's: no table at all (k_probe_sorted)
+        int lookup_key = -1;
+        if (pa.nkey > 0 && arms_here == 1 && join_lookup_mode() != 0 && only_arm->t->sorted_s && only_arm->fs < 0) {
+          for (int c = 0; c < pa.nkey; ++c)
+            if (only_arm->src[pa.key_src[c]] == 0) lookup_key = c;
+          const double i_rows = k - 1 < (int)rows_hint.size() ? rows_hint[k - 1] : (double)I.cap;
+          // (measured at LUBM-1300 and LUBM-100: from 2^20 rows on, with at most half as many rows to look up; 2^18 or 2^19 rows
+          // lose to a pass over so small a table, as many rows to look up as the table holds lose to the hash join)
+          if (join_lookup_mode() < 0 && !(only_arm->t->rows >= (1u << 20) && 2.0 * i_rows <= (double)only_arm->t->rows)) lookup_key = -1;
+        }
+        const bool lookup = lookup_key >= 0;
         bool reverse = false;
-        if (pa.nkey > 0 && !small && arms_here == 1 && join_reverse_mode() != 0) {
+        if (pa.nkey > 0 && !small && !lookup && arms_here == 1 && join_reverse_mode() != 0) {
           const double i_est = k - 1 < (int)rows_hint.size() ? rows_hint[k - 1] : (double)I.cap;
           reverse = join_reverse_mode() > 0 || 2.0 * std::min<double>(r.est, (double)only_arm->t->rows) <= i_est;
         }
@@ -1483,7 +1566,7 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           heads_words += hsize;
           tmp32.emplace_back(pool, std::max<uint64_t>(arm_rows, 1));
           pa.next = tmp32.back().p; pa.hmask = hsize - 1; pa.near = join_near_bits(); pa.near_b = join_near_b_bits();
-        } else if (pa.nkey > 0 && !small) {
+        } else if (pa.nkey > 0 && !small && !lookup) {
           // Chained table: any number of heads is correct, fewer only means longer chains. Two heads per row
           // that is expected (four times the planner's estimate, to be safe), never fewer than a sixteenth of the
           // rows that could arrive: the heads of all steps are filled before the first scan and read at random by the
@@ -1534,6 +1617,18 @@ static dx_result* run_query_in(dx_ctx* ctx, const std::string& sql, int mode, De
           step_cap[k] = cap;
         }
         pa.out = out;
+        if (lookup) {
+          pa.arm = arm_dev(r, *only_arm);
+          const uint32_t icap = I.cap;
+          const ProbeArgs pv = pa;
+          const int s_key = lookup_key;
+          launches.push_back([=](const Prologue&, const Epilogue& ep, unsigned) {
+            hipLaunchKernelGGL(k_probe_sorted, dim3(tile_grid(icap, 1)), dim3(256), 0, s, pv, s_key, ep);
+          });
+          I = out;
+          for (int c : new_cls) I_cls.push_back(c);
+          continue;
+        }
         if (reverse) {
           pa.arm = arm_dev(r, *only_arm);
           const uint64_t arm_rows = only_arm->t->rows;

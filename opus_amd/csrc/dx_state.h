@@ -113,6 +113,8 @@ struct CatalogTable {
   uint64_t rows = 0;
   uint64_t distinct_s = 0, distinct_o = 0;  // feed the join-order estimates; counted when a plan first needs them
   bool stats_pending = false;               // loaded, not counted yet
+  bool sorted_s = false;                    // checked when the statistics are counted: s never decreases from one row to the next
+  bool unsorted_s = false;                  // found so: the distinct subjects are counted like the objects, through a byte per term
   // A directory that several predicates share (their names sanitise alike) is read as one table and can hold a
   // row twice. Spark's UNION removes such rows, a plain sub-select keeps them: UNION arms read this copy instead.
   bool several_sources = false;             // more than one slice / file behind the view
@@ -155,7 +157,8 @@ struct dx_ctx {
   dx::MeasureState measures;
   dx::LayoutTimes layout_times;
   std::map<std::string, dx::CatalogTable> catalog;   // by view name
-  std::map<std::string, std::pair<uint64_t, uint64_t>> table_stats;  // by table key: distinct s, distinct o
+  struct TableStats { uint64_t first = 0, second = 0; bool sorted_s = false; };
+  std::map<std::string, TableStats> table_stats;  // by table key: distinct s, distinct o, whether s is in ascending order
   // Vertical-partition tables brought in from a layout's Parquet files (dx_import_layout), by table key: resident id
   // columns that dx_load_table hands out without copying, like the tables of a partition run.
   struct ImportedTable { dx::DevBuf<int64_t> s, o; uint64_t rows = 0; bool several_files = false; };

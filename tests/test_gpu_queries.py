@@ -61,7 +61,9 @@ def test_lubm_query_counts_and_bindings(loaded, lubm1, name):
                                       {"DX_JOIN_STRIPE_ROWS": "1", "DX_JOIN_NO_LDS": "1"},
                                       {"DX_JOIN_REVERSE": "1", "DX_JOIN_NO_LDS": "1"},
                                       {"DX_JOIN_REVERSE": "1", "DX_JOIN_NO_LDS": "1", "DX_JOIN_STRIPE_ROWS": "1"},
-                                      {"DX_JOIN_REVERSE": "0", "DX_JOIN_NO_LDS": "1"}],
+                                      {"DX_JOIN_REVERSE": "0", "DX_JOIN_NO_LDS": "1"},
+                                      {"DX_JOIN_LOOKUP": "1"}, {"DX_JOIN_LOOKUP": "1", "DX_JOIN_STRIPE_ROWS": "1"},
+                                      {"DX_JOIN_LOOKUP": "0"}],
                          ids=lambda d: ",".join("%s=%s" % (k[3:], v) for k, v in sorted(d.items())))
 def test_join_variants_change_nothing(loaded, lubm1, monkeypatch, switches):
     """The ways a join step can be carried out, each forced on every step it can apply to:
@@ -70,7 +72,10 @@ def test_join_variants_change_nothing(loaded, lubm1, monkeypatch, switches):
       LUBM-1 produces; 1: whenever possible, 0: never);
     * the hash table is built over the arriving table's rows and the intermediate streamed past it when the table
       is expected to be the smaller side (DX_JOIN_REVERSE 1: whenever possible, 0: never);
-    * DX_JOIN_NO_LDS keeps every join's table in HBM (small intermediates otherwise get theirs in LDS).
+    * DX_JOIN_NO_LDS keeps every join's table in HBM (small intermediates otherwise get theirs in LDS);
+    * no table at all when the arriving table is stored in ascending order of its subjects and the join's key holds
+      that subject: every row of the intermediate bisects the table (DX_JOIN_LOOKUP 1: whenever possible, 0: never;
+      by itself only for tables of 2^20 rows and more).
     Counts and bindings are the oracle's every time."""
     from opus_amd.engine import DX_QUERY_BINDINGS, DX_QUERY_COUNT
     from oracle.query_oracle import run_query
