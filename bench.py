@@ -742,9 +742,12 @@ def main():
                                    "geomean_frac": math.exp(sum(math.log(max(v["frac"], 1e-12)) for v in per.values()) / len(per)),
                                    "total_frac": sum(v["bytes"] for v in per.values()) / max(sum(v["device_ms"] for v in per.values()), 1e-9) / 1e6 / HBM_PEAK_GBS,
                                    "per_query": per,
-                                   "note": "device time between the events around a statement's kernels; the tables of these statements "
-                                           "hold 0.03-2.4 M rows, so a statement moves 1-40 MB: it is bound by the latency of its chain of "
-                                           "short kernels, not by bandwidth"}
+                                   "note": "bytes = 16 per row of every table the statement names (the survey's figure), device time by the "
+                                           "device's clock from the first kernel's begin to the last kernel's end. A statement that filters on "
+                                           "one column reads only that column of the rows that fail, and one that bisects a sorted table "
+                                           "reads a few lines of it: both move fewer bytes than the figure, so frac is no measure of HBM "
+                                           "traffic and can pass 1 for a single-column count. At LUBM-100 the tables hold 0.03-2.4 M rows "
+                                           "(1-40 MB a statement): bound by the latency of a chain of short kernels, not by bandwidth"}
         if measures is not None:
             out["instance_measures"] = {"device_ms": measures["device_ms"], "classes": measures["n_classes"],
                                         "cc_groups": measures["n_cc"], "cc_rows": measures["n_cc_rows"]}
