@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(256) k_probe_sorted(ProbeArgs p, int s_key, Ep
       uint32_t a = 0, b = rows;
       while (a < b) {
         const uint32_t m = a + (b - a) / 2;
-        if (as[m] < ks) a = m + 1; else b = m;
+        if ((uint64_t)as[m] < (uint64_t)ks) a = m + 1; else b = m;  // the order k_count_changes looked at
       }
       lo = a;
       for (uint32_t i = lo; i < rows && as[i] == ks; ++i) {
