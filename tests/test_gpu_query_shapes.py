@@ -63,6 +63,16 @@ def test_reference_query_shapes_on_heterogeneous_data():
                     rows, cols = res.rows()
                     assert res.count == want["count"], (q, tr)
                     assert cols == want["columns"] and rows == want["rows"], (q, tr)
+                    # the same statement with every join that can bisect its sorted table doing so, and with every hash table
+                    # built over the arriving table: other ways to the same rows
+                    for switch in ("DX_JOIN_LOOKUP", "DX_JOIN_REVERSE"):
+                        os.environ[switch] = "1"
+                        try:
+                            other = e.query(next(iter(qm.values())), DX_QUERY_BINDINGS)
+                            assert other.count == want["count"] and other.rows()[0] == want["rows"], (switch, q, tr)
+                            other.close()
+                        finally:
+                            del os.environ[switch]
                     answered += 1
                     nonempty += want["count"] > 0
                     with_var_pred += any(tp[1].startswith("?") for tp in sh["patterns"]) and want["count"] > 0
