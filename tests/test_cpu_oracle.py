@@ -264,3 +264,21 @@ def test_cpu_port_on_threads_equals_one_thread_and_answers_like_sqlite(lubm1):
                     assert ds.count(sql, parts, threads=threads, string_keyed=by_string)[0] == want, (name, threads, by_string)
     finally:
         ds.close()
+
+
+def test_sqlite_oracle_matches_hand_derived_query_answers():
+    """The query path's checker against answers worked out by hand (tests/golden/make_hand_derived_queries.py) over
+    the hand-derived layout: two- and three-pattern joins, constants on either column, bags, UNION as a set, tables of
+    two first-level partitions, and files of two statements folded by their common column (or crossed when there is
+    none), QueryProcessor.scala:184-208. Load_data is the sum over the `partitions` line."""
+    from oracle.query_oracle import run_query
+    layout = json.load(open(os.path.join(HERE, "golden", "hand_derived_2.json")))
+    vp = {tuple(k.split("/", 1)): [tuple(r) for r in v] for k, v in layout["vp"].items()}
+    cases = json.load(open(os.path.join(HERE, "golden", "hand_derived_queries.json")))["cases"]
+    assert len(cases) == 9
+    for c in cases:
+        r = run_query(vp, c["text"])
+        assert r["count"] == c["count"], c["name"]
+        assert r["columns"] == c["columns"], c["name"]
+        assert [list(x) for x in r["rows"]] == c["rows"], c["name"]
+        assert r["load_data"] == c["load_data"], c["name"]
