@@ -3,6 +3,7 @@ either parse or be refused with DX_E_MALFORMED / DX_E_UNSUPPORTED -- never crash
 harness is built with AddressSanitizer; it is host code, no GPU involved)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -74,3 +75,31 @@ def test_mutated_statements_never_crash(harness):
     assert all(v.startswith("OK ") for v in verdicts[:len(base)])                 # the originals parse
     assert all(v.startswith("OK ") or v in ("ERR -74", "ERR -95") for v in verdicts), sorted(set(v for v in verdicts if v.startswith("ERR")))
     assert sum(v.startswith("ERR") for v in verdicts) > 1000                        # and the mutants really are broken
+
+
+def test_several_statements_parse_as_one_joined_statement(harness):
+    """A file's statements reach the parser separated by U+001E (dx_query_joined): they come out as one statement with
+    all their sub-selects, the equalities of each and one more per output column two of them share
+    (QueryProcessor.customJoin, QueryProcessor.scala:197-208); the hand-derived files of tests/golden are the inputs."""
+    import json
+    sys.path.insert(0, ROOT)
+    from oracle.query_oracle import parse_translated_file
+    cases = json.load(open(os.path.join(HERE, "golden", "hand_derived_queries.json")))["cases"]
+    lines, expect = [], []
+    for c in cases:
+        stmts = list(parse_translated_file(c["text"])[0].values())
+        lines.append("\x1e".join(stmts))
+        expect.append((c["name"], len(stmts), len(c["columns"])))
+    p = subprocess.run([harness], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    verdicts = p.stdout.split("\n")[:-1]
+    assert len(verdicts) == len(lines)
+    for v, (name, n_stmts, n_cols) in zip(verdicts, expect):
+        assert v.startswith("OK "), (name, v)
+        selected, subs, conds = (int(x) for x in v.split()[1:])
+        assert selected == n_cols, (name, v)          # every output column once, a shared one not twice
+        assert subs >= n_stmts, (name, v)
+    two = dict((e[0], v) for v, e in zip(verdicts, expect))
+    assert two["two_statements_joined_on_their_common_column"].split()[1:] == ["3", "2", "1"]   # X, Y, N; two sub-selects; X = X
+    assert two["two_statements_without_a_common_column"].split()[1:] == ["2", "2", "0"]         # no equality: a cross product
